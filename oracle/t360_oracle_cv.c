@@ -1,0 +1,344 @@
+/*
+ * oracle/t360_oracle_cv.c -- CPU ORACLE (test infrastructure only; see t360_oracle.h)
+ *
+ * ** PARITY UNPINNED at this boundary. **
+ * The per-frame arithmetic of the reference lives in OpenCV (cv::remap at
+ * VideoFrameTransform.cpp:748-754, cv::sepFilter2D at :189-197), an un-vendored dependency
+ * with no version pin (CMakeLists.txt:11) that is not installed in this image; the reference
+ * ships no tests or golden images.  This file restates the published OpenCV 4.x algorithms
+ * (modules/imgproc/src/imgwarp.cpp: initInterTab1D/2D, RemapInvoker, remapNearest/Bilinear/
+ * Bicubic/Lanczos4; modules/imgproc/src/filter.dispatch.cpp + filter.simd.hpp: getKernelType,
+ * createSeparableLinearFilter, FilterEngine ROI rules) following SURVEY.md Appendix A.
+ * Known residual uncertainty (each <= 1 LSB, on exact ties only): OpenCV's SIMD column pass
+ * of the fixed-point separable filter rounds half-to-even where this integer form rounds
+ * half-up; the float filter path's tap pairing order.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "t360_oracle.h"
+
+#define INTER_BITS 5
+#define INTER_TAB_SIZE 32
+#define INTER_TAB_SIZE2 (INTER_TAB_SIZE * INTER_TAB_SIZE)
+#define INTER_REMAP_COEF_BITS 15
+#define INTER_REMAP_COEF_SCALE (1 << INTER_REMAP_COEF_BITS)
+
+#ifndef CV_PI
+#define CV_PI 3.1415926535897932384626433832795
+#endif
+
+/* cvRound: round half to even under the default rounding mode */
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline short sat_s16(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+static inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+/* saturate_cast<short>(float) = saturate(cvRound(v)) */
+static inline short sat_s16_f(float v) { return sat_s16(cv_round_f(v)); }
+
+/* cv::borderInterpolate (core/src/copy.cpp) */
+int t360o_border_interpolate(int p, int len, int borderType) {
+  if ((unsigned)p < (unsigned)len) return p;
+  if (borderType == T360O_BORDER_REPLICATE) {
+    p = p < 0 ? 0 : len - 1;
+  } else if (borderType == T360O_BORDER_REFLECT || borderType == T360O_BORDER_REFLECT_101) {
+    int delta = borderType == T360O_BORDER_REFLECT_101;
+    if (len == 1) return 0;
+    do {
+      if (p < 0)
+        p = -p - 1 + delta;
+      else
+        p = len - 1 - (p - len) - delta;
+    } while ((unsigned)p >= (unsigned)len);
+  } else if (borderType == T360O_BORDER_WRAP) {
+    if (p < 0) p -= ((p - len + 1) / len) * len;
+    if (p >= len) p %= len;
+  } else if (borderType == T360O_BORDER_CONSTANT) {
+    p = -1;
+  }
+  return p;
+}
+
+/* ---- 1-D coefficient generators (imgwarp.cpp) ---- */
+static void interpolate_linear(float x, float* c) {
+  c[0] = 1.f - x;
+  c[1] = x;
+}
+static void interpolate_cubic(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+static void interpolate_lanczos4(float x, float* c) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0},  {-s45, -s45}, {0, 1},  {s45, -s45},
+                                 {-1, 0}, {s45, s45},   {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) c[i] = 0;
+    c[3] = 1;
+    return;
+  }
+  float sum = 0;
+  double y0 = -(x + 3) * CV_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; i++) {
+    double y = -(x + 3 - i) * CV_PI * 0.25;
+    c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += c[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+
+/* ---- 2-D fixed-point table (initInterTab2D) ---- */
+static int16_t g_tab_linear[INTER_TAB_SIZE2 * 4];
+static int16_t g_tab_cubic[INTER_TAB_SIZE2 * 16];
+static int16_t g_tab_lanczos[INTER_TAB_SIZE2 * 64];
+static int g_tab_ready[5];
+
+static void build_tab(int interp, int16_t* itab_base, int ksize) {
+  float tab1[8 * INTER_TAB_SIZE];
+  float scale = 1.f / INTER_TAB_SIZE;
+  for (int i = 0; i < INTER_TAB_SIZE; i++) {
+    float* t = tab1 + i * ksize;
+    if (interp == LINEAR)
+      interpolate_linear(i * scale, t);
+    else if (interp == CUBIC)
+      interpolate_cubic(i * scale, t);
+    else
+      interpolate_lanczos4(i * scale, t);
+  }
+  for (int i = 0; i < INTER_TAB_SIZE; i++)
+    for (int j = 0; j < INTER_TAB_SIZE; j++) {
+      int16_t* itab = itab_base + (size_t)(i * INTER_TAB_SIZE + j) * ksize * ksize;
+      int isum = 0;
+      for (int k1 = 0; k1 < ksize; k1++) {
+        float vy = tab1[i * ksize + k1];
+        for (int k2 = 0; k2 < ksize; k2++) {
+          float v = vy * tab1[j * ksize + k2];
+          isum += itab[k1 * ksize + k2] = sat_s16_f(v * INTER_REMAP_COEF_SCALE);
+        }
+      }
+      if (isum != INTER_REMAP_COEF_SCALE) {
+        int diff = isum - INTER_REMAP_COEF_SCALE;
+        int ksize2 = ksize / 2, Mk1 = ksize2, Mk2 = ksize2, mk1 = ksize2, mk2 = ksize2;
+        /* For ksize == 2 OpenCV's scan indexes past the 2x2 block; that case cannot occur
+         * because bilinear products (k/32)*(m/32)*32768 are integers summing to 32768. */
+        for (int k1 = ksize2; k1 < ksize2 + 2; k1++)
+          for (int k2 = ksize2; k2 < ksize2 + 2; k2++) {
+            if (itab[k1 * ksize + k2] < itab[mk1 * ksize + mk2])
+              mk1 = k1, mk2 = k2;
+            else if (itab[k1 * ksize + k2] > itab[Mk1 * ksize + Mk2])
+              Mk1 = k1, Mk2 = k2;
+          }
+        if (diff < 0)
+          itab[Mk1 * ksize + Mk2] = (short)(itab[Mk1 * ksize + Mk2] - diff);
+        else
+          itab[mk1 * ksize + mk2] = (short)(itab[mk1 * ksize + mk2] - diff);
+      }
+    }
+}
+
+const int16_t* t360o_inter_tab(int interp, int* ksize) {
+  int16_t* tab;
+  int ks;
+  switch (interp) {
+    case LINEAR: tab = g_tab_linear; ks = 2; break;
+    case CUBIC: tab = g_tab_cubic; ks = 4; break;
+    case LANCZOS4: tab = g_tab_lanczos; ks = 8; break;
+    default: return NULL;
+  }
+  if (!g_tab_ready[interp]) {
+    build_tab(interp, tab, ks);
+    __sync_synchronize();
+    g_tab_ready[interp] = 1;
+  }
+  if (ksize) *ksize = ks;
+  return tab;
+}
+
+/* ---- cv::remap, CV_8UC1 source, CV_32FC2 map, no second map ---- */
+void t360o_remap_rows(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw,
+                      int dh, size_t dstep, const float* map, int interp, int borderType,
+                      int row0, int row1) {
+  (void)dh;
+  if (interp == NEAREST) {
+    /* RemapInvoker: XY = saturate_cast<short>(map); remapNearest */
+    for (int dy = row0; dy < row1; dy++) {
+      const float* m = map + (size_t)dy * dw * 2;
+      uint8_t* D = dst + (size_t)dy * dstep;
+      for (int dx = 0; dx < dw; dx++) {
+        int sx = sat_s16_f(m[dx * 2]);
+        int sy = sat_s16_f(m[dx * 2 + 1]);
+        if ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) {
+          D[dx] = src[(size_t)sy * sstep + sx];
+        } else if (borderType == T360O_BORDER_REPLICATE) {
+          sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
+          sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+          D[dx] = src[(size_t)sy * sstep + sx];
+        } else if (borderType == T360O_BORDER_CONSTANT) {
+          D[dx] = 0;
+        } else if (borderType != T360O_BORDER_TRANSPARENT) {
+          sx = t360o_border_interpolate(sx, sw, borderType);
+          sy = t360o_border_interpolate(sy, sh, borderType);
+          D[dx] = src[(size_t)sy * sstep + sx];
+        }
+      }
+    }
+    return;
+  }
+
+  int ksize;
+  const int16_t* wtab = t360o_inter_tab(interp, &ksize);
+  if (!wtab) return;
+  const int half = ksize / 2 - 1; /* footprint origin = (ix - half, iy - half) */
+  const int borderType1 = borderType != T360O_BORDER_TRANSPARENT ? borderType : T360O_BORDER_REFLECT_101;
+  /* fast-path extent: remapBilinear uses (w-1,h-1) on the top-left tap, bicubic (w-3,h-3),
+   * lanczos4 (w-7,h-7): footprint entirely inside */
+  const unsigned width1 = (unsigned)(sw - (ksize - 1) > 0 ? sw - (ksize - 1) : 0);
+  const unsigned height1 = (unsigned)(sh - (ksize - 1) > 0 ? sh - (ksize - 1) : 0);
+
+  for (int dy = row0; dy < row1; dy++) {
+    const float* m = map + (size_t)dy * dw * 2;
+    uint8_t* D = dst + (size_t)dy * dstep;
+    for (int dx = 0; dx < dw; dx++) {
+      /* RemapInvoker, CV_32FC2 branch */
+      int sxq = cv_round_f(m[dx * 2] * INTER_TAB_SIZE);
+      int syq = cv_round_f(m[dx * 2 + 1] * INTER_TAB_SIZE);
+      int fxy = (syq & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (sxq & (INTER_TAB_SIZE - 1));
+      int cx = sat_s16(sxq >> INTER_BITS);
+      int cy = sat_s16(syq >> INTER_BITS);
+      const int16_t* w = wtab + (size_t)fxy * ksize * ksize;
+      int sx = cx - half, sy = cy - half;
+      int sum = 0;
+      if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+        const uint8_t* S = src + (size_t)sy * sstep + sx;
+        for (int r = 0; r < ksize; r++, S += sstep, w += ksize)
+          for (int c = 0; c < ksize; c++) sum += S[c] * w[c];
+      } else {
+        if (borderType == T360O_BORDER_TRANSPARENT) {
+          if (ksize == 2) continue; /* remapBilinear skips every outlier for cn != 3 */
+          if ((unsigned)cx >= (unsigned)sw || (unsigned)cy >= (unsigned)sh) continue;
+        }
+        if (borderType1 == T360O_BORDER_CONSTANT &&
+            (sx >= sw || sx + ksize <= 0 || sy >= sh || sy + ksize <= 0)) {
+          D[dx] = 0;
+          continue;
+        }
+        int xi[8], yi[8];
+        for (int i = 0; i < ksize; i++) {
+          xi[i] = t360o_border_interpolate(sx + i, sw, borderType1);
+          yi[i] = t360o_border_interpolate(sy + i, sh, borderType1);
+        }
+        for (int r = 0; r < ksize; r++, w += ksize) {
+          if (yi[r] < 0) continue;
+          const uint8_t* S = src + (size_t)yi[r] * sstep;
+          for (int c = 0; c < ksize; c++)
+            if (xi[c] >= 0) sum += S[xi[c]] * w[c];
+        }
+      }
+      /* FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS> */
+      D[dx] = sat_u8((sum + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS);
+    }
+  }
+}
+
+/* ---- cv::getKernelType, anchor = kernel centre ---- */
+enum { K_SYMMETRICAL = 1, K_ASYMMETRICAL = 2, K_SMOOTH = 4, K_INTEGER = 8 };
+int t360o_kernel_type(const float* k, int len) {
+  double sum = 0;
+  int type = K_SMOOTH + K_INTEGER;
+  /* 1-D kernel with anchor*2+1 == len (len is always odd here) */
+  if ((len & 1) == 1) type |= (K_SYMMETRICAL + K_ASYMMETRICAL);
+  for (int i = 0; i < len; i++) {
+    double a = k[i], b = k[len - i - 1];
+    if (a != b) type &= ~K_SYMMETRICAL;
+    if (a != -b) type &= ~K_ASYMMETRICAL;
+    if (a < 0) type &= ~K_SMOOTH;
+    if (a != (double)cv_round_d(a)) type &= ~K_INTEGER;
+    sum += a;
+  }
+  if (fabs(sum - 1) > FLT_EPSILON * (fabs(sum) + 1)) type &= ~K_SMOOTH;
+  return type;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ---- cv::sepFilter2D on an ROI of a parent image (no BORDER_ISOLATED) ---- */
+int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep, uint8_t* dparent,
+                        size_t dstep, int left, int top, int width, int height, const float* kx,
+                        int kx_len, const float* ky, int ky_len) {
+  /* cv::Mat::operator()(Rect) asserts the ROI is inside the matrix */
+  if (left < 0 || top < 0 || width < 0 || height < 0 || left + width > pw || top + height > ph)
+    return -1;
+  if (width == 0 || height == 0) return 1;
+  const int rx = kx_len / 2, ry = ky_len / 2; /* anchor (-1,-1) -> centre */
+  const int rtype = t360o_kernel_type(kx, kx_len);
+  const int ctype = t360o_kernel_type(ky, ky_len);
+  const int fixedpt = rtype == (K_SMOOTH + K_SYMMETRICAL) && ctype == (K_SMOOTH + K_SYMMETRICAL);
+  const int nrows = height + 2 * ry;
+
+  if (fixedpt) {
+    int* kxi = (int*)malloc(sizeof(int) * (size_t)kx_len);
+    int* kyi = (int*)malloc(sizeof(int) * (size_t)ky_len);
+    /* Mat::convertTo(CV_32S, 256): saturate_cast<int>(v * 256) in double -> cvRound */
+    for (int i = 0; i < kx_len; i++) kxi[i] = cv_round_d((double)kx[i] * 256.0);
+    for (int i = 0; i < ky_len; i++) kyi[i] = cv_round_d((double)ky[i] * 256.0);
+    int* rows = (int*)malloc(sizeof(int) * (size_t)nrows * (size_t)width);
+    for (int r = 0; r < nrows; r++) {
+      const uint8_t* S = parent + (size_t)clampi(top - ry + r, 0, ph - 1) * pstep;
+      int* R = rows + (size_t)r * width;
+      for (int x = 0; x < width; x++) {
+        int s = 0;
+        for (int k = 0; k < kx_len; k++) s += kxi[k] * S[clampi(left + x - rx + k, 0, pw - 1)];
+        R[x] = s;
+      }
+    }
+    for (int y = 0; y < height; y++) {
+      uint8_t* D = dparent + (size_t)(top + y) * dstep + left;
+      for (int x = 0; x < width; x++) {
+        int s = 0;
+        for (int k = 0; k < ky_len; k++) s += kyi[k] * rows[(size_t)(y + k) * width + x];
+        /* FixedPtCastEx<int, uchar>(16) */
+        D[x] = sat_u8((s + (1 << 15)) >> 16);
+      }
+    }
+    free(rows);
+    free(kxi);
+    free(kyi);
+    return 1;
+  }
+
+  /* float path: RowFilter<uchar,float> then (Symm)ColumnFilter<Cast<float,uchar>> */
+  float* rows = (float*)malloc(sizeof(float) * (size_t)nrows * (size_t)width);
+  for (int r = 0; r < nrows; r++) {
+    const uint8_t* S = parent + (size_t)clampi(top - ry + r, 0, ph - 1) * pstep;
+    float* R = rows + (size_t)r * width;
+    for (int x = 0; x < width; x++) {
+      float s = kx[0] * S[clampi(left + x - rx, 0, pw - 1)];
+      for (int k = 1; k < kx_len; k++) s += kx[k] * S[clampi(left + x - rx + k, 0, pw - 1)];
+      R[x] = s;
+    }
+  }
+  const int symmetric = (ctype & K_SYMMETRICAL) != 0;
+  for (int y = 0; y < height; y++) {
+    uint8_t* D = dparent + (size_t)(top + y) * dstep + left;
+    for (int x = 0; x < width; x++) {
+      float s;
+      if (symmetric) {
+        s = ky[ry] * rows[(size_t)(y + ry) * width + x];
+        for (int k = 1; k <= ry; k++)
+          s += ky[ry + k] * (rows[(size_t)(y + ry + k) * width + x] + rows[(size_t)(y + ry - k) * width + x]);
+      } else {
+        s = ky[0] * rows[(size_t)y * width + x];
+        for (int k = 1; k < ky_len; k++) s += ky[k] * rows[(size_t)(y + k) * width + x];
+      }
+      D[x] = sat_u8(cv_round_f(s));
+    }
+  }
+  free(rows);
+  return 0;
+}
