@@ -1,0 +1,91 @@
+/*
+ * transform360-mi355x: ADDITIVE entry points (not present in the reference).
+ *
+ * The four reference symbols (VideoFrameTransformHandler.h) are synchronous and take one
+ * plane of one frame; through host pointers they are PCIe-bound.  A caller
+ * that keeps frames resident in HBM -- a hardware decoder feeding an encoder, the benchmark,
+ * the multi-GPU frame-sharding driver -- uses the calls below instead: same handle, same maps
+ * (VideoFrameTransform_generateMapForPlane must have been called for every map index used),
+ * same arithmetic, but whole batches of frames per launch on a caller-chosen HIP stream.
+ *
+ * All functions return 1 on success and 0 on failure (message on stdout), like the
+ * reference's C entry points (reference VideoFrameTransformHandler.cpp:26-64).
+ * Plain C ABI: pointers, integers, no HIP or C++ types in the signatures; a hipStream_t is
+ * passed as void*.
+ */
+#ifndef TRANSFORM360_T360_DEVICE_H
+#define TRANSFORM360_T360_DEVICE_H
+
+#include <stdint.h>
+
+#include "VideoFrameTransformHandler.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One image plane inside a frame buffer (what one call of
+ * VideoFrameTransform_transformFramePlane describes, reference vf_transform360.c:368-397). */
+typedef struct T360PlaneDesc {
+  int64_t in_offset;  /* byte offset of the plane inside one INPUT frame  */
+  int64_t out_offset; /* byte offset of the plane inside one OUTPUT frame */
+  int in_stride;      /* bytes per input row  (>= in_width)  */
+  int out_stride;     /* bytes per output row (>= out_width) */
+  int in_width, in_height;
+  int out_width, out_height;
+  int map_index;      /* transformMatPlaneIndex: 0 = luma-shaped map, 1 = chroma-shaped map */
+} T360PlaneDesc;
+
+/* Library version string, e.g. "transform360-mi355x 0.1 (gfx950)". */
+const char* T360_version(void);
+
+/* Number of visible HIP devices (0 if the runtime cannot be initialised). */
+int T360_deviceCount(void);
+
+/* Use `hip_stream` (a hipStream_t) for all device work of this handle; NULL restores the
+ * handle's own stream.  Device-pointer calls of the reference ABI still synchronise before
+ * returning; the batch calls below do not. */
+int T360_setStream(VideoFrameTransform* transform, void* hip_stream);
+
+/* Block until everything queued on the handle's stream has finished. */
+int T360_synchronize(VideoFrameTransform* transform);
+
+/* Transform `n_frames` frames that live in device memory:
+ *   frame k input  = d_in  + k * in_frame_bytes,  frame k output = d_out + k * out_frame_bytes,
+ * each holding `n_planes` planes laid out as `planes[]` says.  Asynchronous on the handle's
+ * stream.  Equivalent to n_frames * n_planes calls of VideoFrameTransform_transformFramePlane. */
+int T360_transformFrames(VideoFrameTransform* transform,
+                         const uint8_t* d_in, int64_t in_frame_bytes,
+                         uint8_t* d_out, int64_t out_frame_bytes,
+                         int n_frames, const T360PlaneDesc* planes, int n_planes);
+
+/* Low-pass stage only (reference filterPlane, VideoFrameTransform.cpp:621-704) on one
+ * device-resident plane; asynchronous.  For parity tests of the segmented filter. */
+int T360_filterPlane(VideoFrameTransform* transform, const uint8_t* d_in, uint8_t* d_out,
+                     int width, int height, int in_stride, int out_stride, int map_index);
+
+/* ---- introspection of init-time state (parity tests against the oracle) ---- */
+
+/* Size of the warp map of `map_index` (the reference's warpMats_[idx], VideoFrameTransform.h:148). */
+int T360_getMapSize(VideoFrameTransform* transform, int map_index, int* width, int* height);
+/* Copy the float (x,y) pairs of the warp map to host memory: 2*width*height floats. */
+int T360_copyMap(VideoFrameTransform* transform, int map_index, float* host_dst);
+/* Low-pass segments of `map_index` (segmentFilteringConfigs_/filterKernelsX_/Y_, :150-159). */
+int T360_getSegmentCount(VideoFrameTransform* transform, int map_index);
+/* rect4 = left, top, width, height; lens2 = taps of kX, kY; *fixed_point = 1 if the segment
+ * runs the 8-bit fixed-point filter path, 0 for the float path. */
+int T360_getSegment(VideoFrameTransform* transform, int map_index, int i, int* rect4, int* lens2,
+                    int* fixed_point);
+int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i, float* kx, float* ky);
+
+/* ---- synthetic stream generator (benchmark / tests) ---- */
+
+/* Fill device memory with counter-based noise: byte i = top 8 bits of
+ * splitmix64(seed + i).  Asynchronous on `hip_stream` (NULL = default stream).
+ * The same function evaluated on the host gives identical bytes. */
+int T360_fillNoise(uint8_t* d_dst, int64_t nbytes, uint64_t seed, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSFORM360_T360_DEVICE_H */

@@ -1,0 +1,290 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the exported C ABI, against the CPU
+oracle on the same inputs and against the committed golden vectors.
+
+Bars (BASELINE.json north_star): warp maps bit-exact (float bits), nearest bit-exact,
+bilinear / bicubic / Lanczos4 / low-pass within +-1 LSB of the reference path -- the HIP kernels
+use the oracle's integer formulation, so the tests below demand BIT-EXACT equality with the
+oracle everywhere; the +-1 LSB is left to the oracle-vs-real-OpenCV uncertainty
+(oracle/t360_oracle_cv.c header).
+"""
+import numpy as np
+import pytest
+
+from tests import cases
+from transform360_amd.abi import CUBIC, LANCZOS4, LINEAR, NEAREST, chroma_dims, filter_defaults
+
+pytestmark = pytest.mark.gpu
+
+
+def hx(v):
+    return "%016x" % v
+
+
+@pytest.fixture(scope="module")
+def T(gpu_lib):
+    import torch
+
+    from transform360_amd import handler
+    assert torch.cuda.is_available()
+    return handler
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def padded_cuda(h, w, pad, fill):
+    import torch
+    full = torch.full((h, w + pad), fill, dtype=torch.uint8, device="cuda")
+    return full, full[:, :w]
+
+
+# ---------------------------------------------------------------- projection kernel
+@pytest.mark.parametrize("name", sorted(cases.MAP_CASES))
+def test_map_bit_exact(name, T, oracle_mod, golden):
+    O = oracle_mod
+    ov, dims = cases.MAP_CASES[name]
+    ctx = cases.make_ctx(ov)
+    with T.VideoFrameTransform(ctx) as t:
+        assert t.generateMapForPlane(*dims, 0)
+        m = t.map(0)
+    g = golden["maps"][name]
+    assert m.shape == (g["h"], g["w"], 2)
+    q, nn = O.quantize_map(m)
+    got = (hx(O.fnv1a64(m)), hx(O.fnv1a64(q)), hx(O.fnv1a64(nn)))
+    if got != (g["f32"], g["q"], g["nn"]):
+        o = O.Oracle(ctx)
+        assert o.generateMapForPlane(*dims, 0)
+        ref = o.map(0)
+        bad = np.argwhere(m.view(np.uint32) != ref.view(np.uint32))
+        r, c, k = bad[0]
+        pytest.fail("%s: %d of %d coordinates differ from the reference map; first at (%d,%d)[%d]: "
+                    "gpu %s ref %s" % (name, len(bad), m.size, r, c, k, float(m[r, c, k]).hex(), float(ref[r, c, k]).hex()))
+
+
+def test_unsupported_layout_is_refused_not_faked(T):
+    from transform360_amd.abi import LAYOUT_EAC_32
+    with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_EAC_32)) as t:
+        assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
+        src = dev(np.zeros((512, 1024), np.uint8))
+        dst = dev(np.zeros((256, 384), np.uint8))
+        assert not t.transformFramePlane(src, dst, 0)
+
+
+# ---------------------------------------------------------------- low-pass configuration
+@pytest.mark.parametrize("name", sorted(cases.LOWPASS_CASES))
+def test_lowpass_config_matches(name, T, oracle_mod, golden):
+    O = oracle_mod
+    ov, dims = cases.LOWPASS_CASES[name]
+    with T.VideoFrameTransform(cases.make_ctx(ov)) as t:
+        assert t.generateMapForPlane(*dims, 0)
+        segs = t.segments(0)
+    g = golden["lowpass"][name]
+    assert len(segs) == g["count"]
+    rects = np.array([s[:4] for s in segs], np.int32).reshape(-1, 4)
+    kbits = np.concatenate([np.concatenate([s[4], s[5]]) for s in segs]).astype(np.float32)
+    assert hx(O.fnv1a64(rects)) == g["rects"]
+    assert hx(O.fnv1a64(kbits)) == g["kernels"]
+
+
+# ---------------------------------------------------------------- whole plane, device pointers
+@pytest.mark.parametrize("name", sorted(cases.FRAME_CASES))
+def test_frame_case_device_pointers(name, T, oracle_mod, golden):
+    O = oracle_mod
+    ov, dims, pin, pout = cases.FRAME_CASES[name]
+    in_w, in_h, out_w, out_h = dims
+    ctx = cases.make_ctx(ov)
+    src = cases.case_input(name, in_w, in_h, pin)
+    # oracle
+    o = O.Oracle(ctx, threads=4)
+    assert o.generateMapForPlane(*dims, 0)
+    want = np.zeros((out_h, out_w), np.uint8)
+    assert o.transformFramePlane(src, want, 0)
+    assert hx(O.fnv1a64(want)) == golden["frames"][name]["out"]
+    # HIP path through the reference ABI with device pointers and the same padded strides
+    dsrc_full = dev(np.ascontiguousarray(src.base if src.base is not None else src).reshape(in_h, in_w + pin))
+    dsrc = dsrc_full[:, :in_w]
+    dfull, ddst = padded_cuda(out_h, out_w, pout, 0xA5)
+    with T.VideoFrameTransform(ctx) as t:
+        assert t.generateMapForPlane(*dims, 0)
+        if ctx.enable_low_pass_filter:
+            import torch
+            blur = torch.zeros((in_h, in_w), dtype=torch.uint8, device="cuda")
+            assert t.filterPlane(dsrc, blur, 0) and t.synchronize()
+            wantb = o.filterPlane(src, 0)
+            gotb = blur.cpu().numpy()
+            assert np.array_equal(gotb, wantb), "low-pass stage: %d px differ, max |d| %d" % (
+                (gotb != wantb).sum(), np.abs(gotb.astype(int) - wantb.astype(int)).max())
+        assert t.transformFramePlane(dsrc, ddst, 0, 0)
+    got = ddst.cpu().numpy()
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() == 0, "%s: %d px differ, max |d| = %d" % (name, (diff > 0).sum(), diff.max())
+    assert (dfull[:, out_w:] == 0xA5).all().item()   # only `width` bytes per row may be written
+
+
+# ---------------------------------------------------------------- host pointers (the literal ABI)
+@pytest.mark.parametrize("name", ["cubic", "nearest", "cubic_lpf_32x15", "tiny"])
+def test_frame_case_host_pointers(name, T, golden, oracle_mod):
+    ov, dims, pin, pout = cases.FRAME_CASES[name]
+    in_w, in_h, out_w, out_h = dims
+    src = cases.case_input(name, in_w, in_h, pin)
+    full = np.full((out_h, out_w + pout), 0xA5, np.uint8)
+    dst = full[:, :out_w]
+    with T.VideoFrameTransform(cases.make_ctx(ov)) as t:
+        assert t.generateMapForPlane(*dims, 0)
+        assert t.transformFramePlane(src, dst, 0, 0)     # numpy arrays = host pointers
+    assert hx(oracle_mod.fnv1a64(np.ascontiguousarray(dst))) == golden["frames"][name]["out"]
+    assert (full[:, out_w:] == 0xA5).all()
+
+
+# ---------------------------------------------------------------- vf_transform360.c call sequence
+def test_filter_call_sequence_yuv420p(T, oracle_mod):
+    """_new, two _generateMapForPlane calls (luma dims, chroma dims via ceil-shift), then three
+    _transformFramePlane calls per frame with padded linesizes (vf_transform360.c:141-162, 368-397)."""
+    O = oracle_mod
+    in_w, in_h, out_w, out_h = 1280, 640, 768, 512
+    ctx = filter_defaults(num_vertical_segments=15, num_horizontal_segments=32)
+    cw, ch = chroma_dims(in_w, in_h)
+    ocw, och = chroma_dims(out_w, out_h)
+    o = O.Oracle(ctx, threads=4)
+    with T.VideoFrameTransform(ctx) as t:
+        for idx, d in enumerate([(in_w, in_h, out_w, out_h), (cw, ch, ocw, och)]):
+            assert t.generateMapForPlane(*d, idx) and o.generateMapForPlane(*d, idx)
+        for frame in range(2):
+            for plane in range(3):
+                idx = 1 if plane in (1, 2) else 0
+                iw, ih, ow, oh = (in_w, in_h, out_w, out_h) if plane == 0 else (cw, ch, ocw, och)
+                src = cases.case_input("seq%d_%d" % (frame, plane), iw, ih, 48)
+                want = np.zeros((oh, ow), np.uint8)
+                assert o.transformFramePlane(src, want, idx, plane)
+                full = np.full((oh, ow + 32), 0x11, np.uint8)
+                dst = full[:, :ow]
+                assert t.transformFramePlane(src, dst, idx, plane)
+                assert np.array_equal(dst, want)
+                assert (full[:, ow:] == 0x11).all()
+
+
+# ---------------------------------------------------------------- batch entry point
+def test_batch_equals_per_plane_calls(T, oracle_mod):
+    import torch
+    O = oracle_mod
+    in_w, in_h, out_w, out_h = 960, 480, 384, 256
+    for ov in (dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4)):
+        ctx = filter_defaults(**ov)
+        lin = T.FrameLayout(in_w, in_h, extra_pad=64)
+        lout = T.FrameLayout(out_w, out_h)
+        n = 5
+        d_in = torch.empty(n * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        for k in range(n):
+            T.fill_noise(d_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes], T.frame_seed(k))
+        d_out = torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        o = O.Oracle(ctx, threads=4)
+        with T.VideoFrameTransform(ctx) as t:
+            for idx, k in ((0, 0), (1, 1)):
+                d = (*lin.dims[k], *lout.dims[k])
+                assert t.generateMapForPlane(*d, idx) and o.generateMapForPlane(*d, idx)
+            assert t.setStream(torch.cuda.current_stream())
+            assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
+            assert t.synchronize()
+            h_in = d_in.cpu().numpy()
+            h_out = d_out.cpu().numpy()
+            for k in range(n):
+                fin = h_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes]
+                # the device generator and its host restatement agree byte for byte
+                assert np.array_equal(fin, T.noise_bytes(lin.frame_bytes, T.frame_seed(k)))
+                fout = h_out[k * lout.frame_bytes:(k + 1) * lout.frame_bytes]
+                for p in range(3):
+                    want = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
+                    assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
+                    assert np.array_equal(lout.plane_view(fout, p), want), (k, p)
+
+
+# ---------------------------------------------------------------- full-size configs (BASELINE)
+def _full_size_case(T, O, ov, luma_dims, n_check_rows=None):
+    import torch
+    in_w, in_h, out_w, out_h = luma_dims
+    ctx = filter_defaults(**ov)
+    o = O.Oracle(ctx, threads=8)
+    assert o.generateMapForPlane(*luma_dims, 0)
+    src = T.noise_bytes(in_w * in_h, 0xBA5E).reshape(in_h, in_w)
+    want = np.zeros((out_h, out_w), np.uint8)
+    assert o.transformFramePlane(src, want, 0)
+    with T.VideoFrameTransform(ctx) as t:
+        assert t.generateMapForPlane(*luma_dims, 0)
+        dsrc = dev(src)
+        ddst = torch.zeros((out_h, out_w), dtype=torch.uint8, device="cuda")
+        assert t.transformFramePlane(dsrc, ddst, 0)
+        got = ddst.cpu().numpy()
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() == 0, "%d px differ, max |d| = %d" % ((diff > 0).sum(), diff.max())
+
+
+def test_config1_nearest_full_size(T, oracle_mod):
+    _full_size_case(T, oracle_mod, dict(interpolation_alg=NEAREST, enable_low_pass_filter=0), (1920, 960, 768, 512))
+
+
+def test_config2_bicubic_full_size(T, oracle_mod):
+    _full_size_case(T, oracle_mod, dict(interpolation_alg=CUBIC, enable_low_pass_filter=0), (3840, 1920, 1536, 1024))
+
+
+def test_config3_bicubic_lowpass_full_size(T, oracle_mod):
+    _full_size_case(T, oracle_mod, dict(num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1),
+                    (3840, 1920, 1536, 1024))
+
+
+def test_config4_lanczos_tb_full_size(T, oracle_mod):
+    from tests.cases import TB
+    _full_size_case(T, oracle_mod, dict(interpolation_alg=LANCZOS4, enable_low_pass_filter=0, **TB),
+                    (7680, 3840, 3072, 4096))
+
+
+# ---------------------------------------------------------------- size-independent properties
+@pytest.mark.parametrize("interp", [NEAREST, LINEAR, CUBIC, LANCZOS4])
+def test_flat_plane_stays_flat(interp, T):
+    """Every Q15 weight entry sums to exactly 32768 -> constant in, same constant out."""
+    import torch
+    with T.VideoFrameTransform(filter_defaults(interpolation_alg=interp, enable_low_pass_filter=0)) as t:
+        assert t.generateMapForPlane(3840, 1920, 1536, 1024, 0)
+        src = torch.full((1920, 3840), 173, dtype=torch.uint8, device="cuda")
+        dst = torch.zeros((1024, 1536), dtype=torch.uint8, device="cuda")
+        assert t.transformFramePlane(src, dst, 0)
+        assert (dst == 173).all().item()
+
+
+def test_nearest_full_size_is_a_gather_of_the_map(T):
+    """Nearest output == input[round(map)] computed independently with torch indexing."""
+    import torch
+    with T.VideoFrameTransform(filter_defaults(interpolation_alg=NEAREST, enable_low_pass_filter=0)) as t:
+        assert t.generateMapForPlane(3840, 1920, 1536, 1024, 0)
+        m = torch.from_numpy(t.map(0)).cuda()
+        src = torch.empty(1920 * 3840, dtype=torch.uint8, device="cuda")
+        T.fill_noise(src, 77)
+        src = src.view(1920, 3840)
+        dst = torch.zeros((1024, 1536), dtype=torch.uint8, device="cuda")
+        assert t.transformFramePlane(src, dst, 0)
+        ix = torch.round(m[..., 0]).long() % 3840    # torch.round is round-half-even like cvRound
+        iy = torch.round(m[..., 1]).long() % 1920
+        assert torch.equal(dst, src[iy, ix])
+
+
+# ---------------------------------------------------------------- error behaviour of the ABI
+def test_error_convention(T, gpu_lib):
+    L = gpu_lib
+    L.VideoFrameTransform_delete(None)                       # delete(NULL) is a no-op (vf.c:334)
+    assert L.VideoFrameTransform_new(None) is None
+    with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
+        src = dev(np.zeros((64, 128), np.uint8))
+        dst = dev(np.zeros((32, 48), np.uint8))
+        assert not t.transformFramePlane(src, dst, 0)          # no map yet -> 0, no crash
+        assert not t.generateMapForPlane(0, 64, 48, 32, 0)
+        assert t.generateMapForPlane(128, 64, 48, 32, 0)
+        assert t.transformFramePlane(src, dst, 0)
+        assert not t.transformFramePlane(src, dst, 1)          # index 1 never generated
+    # interpolation_alg = 3: the reference prints, writes nothing and still returns true (:780-783)
+    with T.VideoFrameTransform(filter_defaults(interpolation_alg=3, enable_low_pass_filter=0)) as t:
+        assert t.generateMapForPlane(128, 64, 48, 32, 0)
+        dst = dev(np.full((32, 48), 9, np.uint8))
+        assert t.transformFramePlane(dev(np.zeros((64, 128), np.uint8)), dst, 0)
+        assert (dst == 9).all().item()

@@ -1,0 +1,29 @@
+// t360_filtercfg.h -- host-side low-pass configuration (see t360_filtercfg.cpp).
+#pragma once
+
+#include <algorithm>
+#include <vector>
+
+#include "t360_internal.h"
+
+namespace t360 {
+
+// One segment: rectangle (SegmentFilteringConfig, reference VideoFrameTransform.h:25-38) plus
+// its two 1-D kernels (filterKernelsX_/Y_, :150-155) and their Q8 integer form.
+struct Segment {
+  int left = 0, top = 0, width = 0, height = 0;
+  std::vector<float> kx, ky;
+  std::vector<int> kx_q8, ky_q8;
+  bool fixed_point = false;
+};
+
+struct FilterConfig {
+  std::vector<Segment> segments;
+};
+
+// Reference calcualteFilteringConfig (VideoFrameTransform.cpp:367-501) for one plane shape.
+// inputWidth/Height: plane size; outputWidth/Height: the SCALED output size (:560-565).
+bool build_filter_config(const FrameTransformContext& ctx, int inputWidth, int inputHeight,
+                         int outputWidth, int outputHeight, FilterConfig* cfg);
+
+}  // namespace t360

@@ -1,0 +1,71 @@
+// t360_internal.h -- types shared by the host side and the HIP kernels of libTransform360.
+//
+// Data layout in HBM:
+//   * frames        : 8-bit planar, caller-described (pointer + row stride per plane)
+//   * warp map      : float2 per output pixel, row-major -- the reference's warpMats_[idx]
+//                     (reference VideoFrameTransform.h:148), kept for introspection/parity
+//   * sample LUT    : one packed 8-byte entry per output pixel derived from the warp map the way
+//                     cv::remap's RemapInvoker derives (XY, A) from a CV_32FC2 map: integer
+//                     source coordinate + 10-bit sub-pixel phase
+//   * weight tables : OpenCV's 1024-entry Q15 2-D coefficient tables (2x2 / 4x4 / 8x8 taps)
+//   * low-pass work : one record per (segment, tile) + packed per-segment 1-D kernels
+#pragma once
+
+#include <stdint.h>
+
+#include "Transform360/VideoFrameTransformHelper.h"
+
+namespace t360 {
+
+constexpr int kMaxMaps = 8;          // transformMatPlaneIndex values accepted (reference uses 0,1)
+constexpr int kInterTabSize = 32;    // cv::INTER_TAB_SIZE (1/32 pixel phases)
+constexpr int kInterBits = 5;        // cv::INTER_BITS
+constexpr int kCoefBits = 15;        // cv::INTER_REMAP_COEF_BITS
+
+// cv::BorderTypes values used on this path
+enum Border : int { kBorderReplicate = 1, kBorderWrap = 3, kBorderReflect101 = 4, kBorderTransparent = 5 };
+
+// One entry of the sample LUT.  For NEAREST ix/iy are the rounded source pixel, frac is 0.
+struct __attribute__((aligned(8))) LutEntry {
+  int16_t ix;     // saturate_cast<short>(round(x*32) >> 5)   (or round(x) for NEAREST)
+  int16_t iy;
+  uint16_t frac;  // (sy & 31) * 32 + (sx & 31)
+  uint16_t pad;
+};
+static_assert(sizeof(LutEntry) == 8, "LutEntry must be 8 bytes");
+
+// Per-pixel-independent inputs of the projection kernel; everything transcendental that does
+// not depend on the pixel is evaluated once on the host with the host libm, exactly where the
+// reference evaluates it per pixel with the same arguments.
+struct MapGenParams {
+  int map_w, map_h;  // scaled output size = warp map size (VideoFrameTransform.cpp:524-526)
+  int in_w, in_h;    // input plane size
+  int input_layout, output_layout;
+  int input_stereo, output_stereo;
+  int vflip;
+  int interp;        // InterpolationAlg, selects the LUT quantisation
+  int offcenter;     // any |fixed_cube_offcenter_*| > 1e-9 (VideoFrameTransform.cpp:1192-1194)
+  int horizontal_offset;
+  float expand_coef, input_expand_coef;
+  float off_x, off_y, off_z;
+  float rot[9];      // float rotation coefficients in the reference's evaluation order (:1240-1244)
+  float hfov, vfov, yaw_deg, pitch_deg;  // FLAT_FIXED
+  float input_pixel_width;               // VideoFrameTransform.cpp:528-531
+};
+
+// One low-pass segment (SegmentFilteringConfig + its kernels, VideoFrameTransform.h:25-38,150-159)
+struct SegmentDev {
+  int left, top, width, height;
+  int kx_off, kx_len;  // into the packed tap arrays (int32 taps and float taps share offsets)
+  int ky_off, ky_len;
+  int fixed_point;     // 1: Q8 x Q8 integer path, 0: float path
+};
+
+// One unit of low-pass work: a tile of one segment (tiles never straddle segments because the
+// filter kernels change at segment borders).
+struct LowpassTile {
+  int seg;
+  int x0, y0, w, h;  // absolute plane coordinates (stereo eye offset already applied)
+};
+
+}  // namespace t360

@@ -1,0 +1,52 @@
+// t360_kernels.h -- launch interfaces of the HIP kernels (internal to libTransform360).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "t360_internal.h"
+
+namespace t360 {
+
+// ---- projection (t360_mapgen.hip) ----
+hipError_t launch_mapgen(const MapGenParams& P, float2* map, LutEntry* lut, hipStream_t stream);
+hipError_t launch_fill_noise(uint8_t* dst, int64_t nbytes, uint64_t seed, hipStream_t stream);
+
+// ---- gather (t360_remap.hip) ----
+// One plane of `nframes` frames: frame f lives at src + f*src_frame_bytes / dst + f*dst_frame_bytes.
+struct GatherArgs {
+  const uint8_t* src;
+  int64_t src_frame_bytes;
+  int sw, sh, sstride;
+  uint8_t* dst;
+  int64_t dst_frame_bytes;
+  int dw, dh, dstride;
+  const LutEntry* lut;   // dw*dh entries
+  const int16_t* wtab;   // 1024 * k*k Q15 weights (unused for NEAREST)
+  int interp;            // InterpolationAlg
+  int border;            // kBorderWrap or kBorderTransparent
+};
+hipError_t launch_remap_gather(const GatherArgs& a, int nframes, hipStream_t stream);
+hipError_t launch_fill_plane(uint8_t* dst, int64_t frame_bytes, int w, int h, int stride, int value,
+                             int nframes, hipStream_t stream);
+
+// ---- segmented separable low-pass (t360_lowpass.hip) ----
+struct LowpassArgs {
+  const uint8_t* src;
+  int64_t src_frame_bytes;
+  int sstride;
+  uint8_t* dst;
+  int64_t dst_frame_bytes;
+  int dstride;
+  int w, h;                   // plane size (replicate border at its edges only)
+  const LowpassTile* tiles;   // ntiles work items
+  int ntiles;
+  const SegmentDev* segs;
+  const int* taps_q8;         // packed integer taps (Q8)
+  const float* taps_f32;      // packed float taps, same offsets
+  int max_rows;               // max over tiles of (tile.h + 2*ry): sizes the LDS row buffer
+  int tile_w;                 // tile width used when the list was built
+};
+hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
+
+}  // namespace t360

@@ -1,0 +1,649 @@
+// t360_transform.cpp -- host side of the handle: init-time state, pointer classification,
+// staging for host buffers, kernel sequencing on a HIP stream.
+//
+// reference call protocol:  _new -> _generateMapForPlane(idx 0, idx 1) ->
+// per frame, per plane _transformFramePlane -> _delete.
+#include "t360_transform.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace t360;
+
+namespace t360 {
+
+bool DeviceBuffer::reserve(size_t bytes) {
+  if (bytes <= bytes_) return true;
+  release();
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  ptr_ = p;
+  bytes_ = bytes;
+  return true;
+}
+
+void DeviceBuffer::release() {
+  if (ptr_) (void)hipFree(ptr_);
+  ptr_ = nullptr;
+  bytes_ = 0;
+}
+
+// ---- OpenCV fixed-point interpolation tables (imgwarp.cpp initInterTab1D/2D), host build ----
+namespace {
+
+void coeffs_linear(float x, float* c) {
+  c[0] = 1.f - x;
+  c[1] = x;
+}
+void coeffs_cubic(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+void coeffs_lanczos4(float x, float* c) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0},  {-s45, -s45}, {0, 1},  {s45, -s45},
+                                 {-1, 0}, {s45, s45},   {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) c[i] = 0;
+    c[3] = 1;
+    return;
+  }
+  const double pi = 3.1415926535897932384626433832795;
+  float sum = 0;
+  const double y0 = -(x + 3) * pi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+  for (int i = 0; i < 8; i++) {
+    const double y = -(x + 3 - i) * pi * 0.25;
+    c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += c[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+
+inline int16_t round_sat_s16(float v) {
+  long r = std::lrintf(v);
+  return (int16_t)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
+}  // namespace
+
+bool build_inter_table(int interp, std::vector<int16_t>* tab, int* ksize_out) {
+  int ks;
+  void (*gen)(float, float*);
+  switch (interp) {
+    case LINEAR: ks = 2; gen = coeffs_linear; break;
+    case CUBIC: ks = 4; gen = coeffs_cubic; break;
+    case LANCZOS4: ks = 8; gen = coeffs_lanczos4; break;
+    default: return false;
+  }
+  const int N = kInterTabSize;
+  std::vector<float> t1((size_t)N * ks);
+  const float scale = 1.f / N;
+  for (int i = 0; i < N; i++) gen(i * scale, &t1[(size_t)i * ks]);
+  tab->assign((size_t)N * N * ks * ks, 0);
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      int16_t* it = tab->data() + (size_t)(i * N + j) * ks * ks;
+      int isum = 0;
+      for (int k1 = 0; k1 < ks; k1++) {
+        const float vy = t1[(size_t)i * ks + k1];
+        for (int k2 = 0; k2 < ks; k2++) {
+          const float v = vy * t1[(size_t)j * ks + k2];
+          isum += it[k1 * ks + k2] = round_sat_s16(v * (float)(1 << kCoefBits));
+        }
+      }
+      if (isum != (1 << kCoefBits)) {
+        // push the rounding residue onto the largest (or smallest) of four "central" taps,
+        // scanning exactly the index window OpenCV scans
+        const int diff = isum - (1 << kCoefBits);
+        const int h = ks / 2;
+        int Mk1 = h, Mk2 = h, mk1 = h, mk2 = h;
+        for (int k1 = h; k1 < h + 2; k1++)
+          for (int k2 = h; k2 < h + 2; k2++) {
+            if (it[k1 * ks + k2] < it[mk1 * ks + mk2])
+              mk1 = k1, mk2 = k2;
+            else if (it[k1 * ks + k2] > it[Mk1 * ks + Mk2])
+              Mk1 = k1, Mk2 = k2;
+          }
+        if (diff < 0)
+          it[Mk1 * ks + Mk2] = (int16_t)(it[Mk1 * ks + Mk2] - diff);
+        else
+          it[mk1 * ks + mk2] = (int16_t)(it[mk1 * ks + mk2] - diff);
+      }
+    }
+  if (ksize_out) *ksize_out = ks;
+  return true;
+}
+
+}  // namespace t360
+
+// -------------------------------------------------------------------------------------------
+
+namespace {
+
+// scoped hipSetDevice
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+      if (hipSetDevice(dev) == hipSuccess) switched = true;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+enum class PtrKind { Host, Device };
+
+PtrKind classify(const void* p) {
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'd memory is unknown to the runtime
+    return PtrKind::Host;
+  }
+  if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return PtrKind::Device;
+  return PtrKind::Host;
+}
+
+inline bool valid_interp(int a) { return a == NEAREST || a == LINEAR || a == CUBIC || a == LANCZOS4; }
+
+constexpr int kTileW = 64;
+constexpr int kTileH = 16;
+
+}  // namespace
+
+VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
+  memcpy(&ctx_, ctx, sizeof(ctx_));  // the caller's block is a stack local (vf_transform360.c:111-141)
+  if (hipGetDevice(&device_) != hipSuccess) {
+    printf("transform360: no usable HIP device (%s)\n", hipGetErrorString(hipGetLastError()));
+    return;
+  }
+  if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
+    printf("transform360: could not create a HIP stream (%s)\n", hipGetErrorString(hipGetLastError()));
+    return;
+  }
+  stream_ = own_stream_;
+  ok_ = true;
+}
+
+VideoFrameTransform::~VideoFrameTransform() {
+  if (!ok_) return;
+  DeviceGuard g(device_);
+  (void)hipStreamSynchronize(stream_);
+  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+bool VideoFrameTransform::check(hipError_t e, const char* what) const {
+  if (e == hipSuccess) return true;
+  printf("transform360: %s failed: %s\n", what, hipGetErrorString(e));
+  (void)hipGetLastError();
+  return false;
+}
+
+bool VideoFrameTransform::setStream(void* s) {
+  DeviceGuard g(device_);
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  stream_ = s ? static_cast<hipStream_t>(s) : own_stream_;
+  return true;
+}
+
+bool VideoFrameTransform::synchronize() {
+  DeviceGuard g(device_);
+  return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+bool VideoFrameTransform::ensureWeights() {
+  if (weights_ready_) return true;
+  const int interp = (int)ctx_.interpolation_alg;
+  if (interp == NEAREST) {
+    weights_ready_ = true;
+    return true;
+  }
+  std::vector<int16_t> tab;
+  int ks = 0;
+  if (!build_inter_table(interp, &tab, &ks)) return false;
+  if (!weights_.reserve(tab.size() * sizeof(int16_t))) return check(hipErrorOutOfMemory, "hipMalloc(weights)");
+  if (!check(hipMemcpy(weights_.as<void>(), tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice),
+             "hipMemcpy(weights)"))
+    return false;
+  weights_ready_ = true;
+  return true;
+}
+
+// reference VideoFrameTransform::generateMapForPlane (VideoFrameTransform.cpp:504-576)
+bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, int outputWidth,
+                                              int outputHeight, int idx) {
+  if (!ok_) return false;
+  if (idx < 0 || idx >= kMaxMaps) {
+    printf("Could not generate map for plane %d. Error: plane index out of range\n", idx);
+    return false;
+  }
+  // the reference asserts these only in debug builds (:511-520); the GPU path needs them true
+  if (inputWidth <= 0 || inputHeight <= 0 || outputWidth <= 0 || outputHeight <= 0 ||
+      !(ctx_.width_scale_factor > 0) || !(ctx_.height_scale_factor > 0)) {
+    printf("Could not generate map for plane %d. Error: invalid plane size\n", idx);
+    return false;
+  }
+  if (inputWidth > 32767 || inputHeight > 32767) {
+    // cv::remap keeps source coordinates as shorts; larger planes are outside its contract
+    printf("Could not generate map for plane %d. Error: input plane larger than 32767\n", idx);
+    return false;
+  }
+  const int olay = (int)ctx_.output_layout;
+  if (!(olay == LAYOUT_CUBEMAP_32 || olay == LAYOUT_CUBEMAP_23_OFFCENTER || olay == LAYOUT_FLAT_FIXED)) {
+    printf("Could not generate map for plane %d. Error: output layout %d is not implemented on the "
+           "HIP path yet\n", idx, olay);
+    return false;
+  }
+  if (ctx_.enable_low_pass_filter &&
+      !(ctx_.num_vertical_segments >= 1 && ctx_.num_horizontal_segments >= 1 &&
+        ctx_.kernel_height_scale_factor > 0)) {
+    printf("Could not generate map for plane %d. Error: invalid low-pass segment counts\n", idx);
+    return false;
+  }
+  DeviceGuard g(device_);
+  PlaneState& p = planes_[idx];
+
+  MapGenParams P;
+  memset(&P, 0, sizeof(P));
+  P.map_w = (int)(ctx_.width_scale_factor * outputWidth + 0.5);    // :524
+  P.map_h = (int)(ctx_.height_scale_factor * outputHeight + 0.5);  // :525-526
+  if (P.map_w <= 0 || P.map_h <= 0) return false;
+  P.in_w = inputWidth;
+  P.in_h = inputHeight;
+  P.input_layout = (int)ctx_.input_layout;
+  P.output_layout = olay;
+  P.input_stereo = (int)ctx_.input_stereo_format;
+  P.output_stereo = (int)ctx_.output_stereo_format;
+  P.vflip = ctx_.vflip;
+  P.interp = (int)ctx_.interpolation_alg;
+  P.expand_coef = ctx_.expand_coef;
+  P.input_expand_coef = ctx_.input_expand_coef;
+  P.off_x = ctx_.fixed_cube_offcenter_x;
+  P.off_y = ctx_.fixed_cube_offcenter_y;
+  P.off_z = ctx_.fixed_cube_offcenter_z;
+  P.offcenter = std::fabs(P.off_x) > 1e-9 || std::fabs(P.off_y) > 1e-9 || std::fabs(P.off_z) > 1e-9;  // :1192-1194
+  P.horizontal_offset = ctx_.is_horizontal_offset;
+  P.hfov = ctx_.fixed_hfov;
+  P.vfov = ctx_.fixed_vfov;
+  P.yaw_deg = ctx_.fixed_yaw;
+  P.pitch_deg = ctx_.fixed_pitch;
+  P.input_pixel_width = 1.0f / inputWidth;  // :528-531
+  if (ctx_.input_stereo_format == STEREO_FORMAT_LR) P.input_pixel_width *= 2;
+  {
+    // :1233-1244 -- double sin/cos of (deg * M_PI / 180.0f) narrowed to float, then the float
+    // coefficient expressions in the reference's association order
+    const float s1 = (float)std::sin(ctx_.fixed_yaw * M_PI / 180.0f);
+    const float s2 = (float)std::sin(ctx_.fixed_pitch * M_PI / 180.0f);
+    const float s3 = (float)std::sin(ctx_.fixed_roll * M_PI / 180.0f);
+    const float c1 = (float)std::cos(ctx_.fixed_yaw * M_PI / 180.0f);
+    const float c2 = (float)std::cos(ctx_.fixed_pitch * M_PI / 180.0f);
+    const float c3 = (float)std::cos(ctx_.fixed_roll * M_PI / 180.0f);
+    P.rot[0] = c1 * c3 + s1 * s2 * s3;
+    P.rot[1] = c3 * s1 * s2 - c1 * s3;
+    P.rot[2] = c2 * s1;
+    P.rot[3] = c2 * s3;
+    P.rot[4] = c2 * c3;
+    P.rot[5] = -s2;
+    P.rot[6] = c1 * s2 * s3 - c3 * s1;
+    P.rot[7] = c1 * c3 * s2 + s1 * s3;
+    P.rot[8] = c1 * c2;
+  }
+
+  const size_t n = (size_t)P.map_w * (size_t)P.map_h;
+  if (!p.map.reserve(n * sizeof(float2)) || !p.lut.reserve(n * sizeof(LutEntry)))
+    return check(hipErrorOutOfMemory, "hipMalloc(map)");
+  if (!check(launch_mapgen(P, p.map.as<float2>(), p.lut.as<LutEntry>(), stream_), "mapgen launch")) return false;
+  if (!ensureWeights()) return false;
+
+  p.in_w = inputWidth;
+  p.in_h = inputHeight;
+  p.out_w = outputWidth;
+  p.out_h = outputHeight;
+  p.map_w = P.map_w;
+  p.map_h = P.map_h;
+  p.tiles_w = p.tiles_h = -1;
+  p.ntiles = 0;
+  p.filter.segments.clear();
+
+  if (ctx_.enable_low_pass_filter) {
+    // the reference appends on a repeated call (:237, :290-294); the duplicates only redo the
+    // same work, so replacing gives identical output
+    if (!build_filter_config(ctx_, inputWidth, inputHeight, P.map_w, P.map_h, &p.filter)) return false;
+    std::vector<SegmentDev> segs;
+    std::vector<int> q8;
+    std::vector<float> f32;
+    for (const Segment& s : p.filter.segments) {
+      SegmentDev d;
+      d.left = s.left;
+      d.top = s.top;
+      d.width = s.width;
+      d.height = s.height;
+      d.kx_off = (int)q8.size();
+      d.kx_len = (int)s.kx.size();
+      q8.insert(q8.end(), s.kx_q8.begin(), s.kx_q8.end());
+      f32.insert(f32.end(), s.kx.begin(), s.kx.end());
+      d.ky_off = (int)q8.size();
+      d.ky_len = (int)s.ky.size();
+      q8.insert(q8.end(), s.ky_q8.begin(), s.ky_q8.end());
+      f32.insert(f32.end(), s.ky.begin(), s.ky.end());
+      d.fixed_point = s.fixed_point ? 1 : 0;
+      segs.push_back(d);
+    }
+    if (!segs.empty()) {
+      if (!p.segs.reserve(segs.size() * sizeof(SegmentDev)) || !p.taps_q8.reserve(q8.size() * sizeof(int)) ||
+          !p.taps_f32.reserve(f32.size() * sizeof(float)))
+        return check(hipErrorOutOfMemory, "hipMalloc(segments)");
+      if (!check(hipMemcpyAsync(p.segs.as<void>(), segs.data(), segs.size() * sizeof(SegmentDev),
+                                hipMemcpyHostToDevice, stream_), "hipMemcpy(segments)") ||
+          !check(hipMemcpyAsync(p.taps_q8.as<void>(), q8.data(), q8.size() * sizeof(int),
+                                hipMemcpyHostToDevice, stream_), "hipMemcpy(taps)") ||
+          !check(hipMemcpyAsync(p.taps_f32.as<void>(), f32.data(), f32.size() * sizeof(float),
+                                hipMemcpyHostToDevice, stream_), "hipMemcpy(taps)"))
+        return false;
+    }
+  }
+  // host vectors above go out of scope: finish the uploads (init-time only)
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  p.valid = true;
+  return true;
+}
+
+// Tile work list of the low-pass for a plane of w x h (reference filterPlane's segment loop,
+// VideoFrameTransform.cpp:630-691: every segment once per eye).
+bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex) {
+  if (p.tiles_w == w && p.tiles_h == h) return true;
+  std::vector<LowpassTile> tiles;
+  int ox[2] = {0, 0}, oy[2] = {0, 0}, eyes = 1;
+  if (ctx_.input_stereo_format == STEREO_FORMAT_LR) {
+    eyes = 2;
+    ox[1] = (int)(0.5 * w);
+  } else if (ctx_.input_stereo_format == STEREO_FORMAT_TB) {
+    eyes = 2;
+    oy[1] = (int)(0.5 * h);
+  }
+  int64_t covered = 0;
+  int max_rows = 0;
+  for (int e = 0; e < eyes; e++)
+    for (size_t i = 0; i < p.filter.segments.size(); i++) {
+      const Segment& s = p.filter.segments[i];
+      const int L = s.left + ox[e], T = s.top + oy[e];
+      if (L < 0 || T < 0 || s.width < 0 || s.height < 0 || L + s.width > w || T + s.height > h) {
+        // cv::Mat::operator()(Rect) throws; filterSegment prints and carries on (:198-203)
+        printf("Could not filter segment for the plane %d. Error: segment outside the plane\n", imagePlaneIndex);
+        continue;
+      }
+      covered += (int64_t)s.width * s.height;
+      const int ry = (int)s.ky.size() / 2;
+      int th = kTileH;
+      const int rows_cap = (160 * 1024) / (kTileW * (int)sizeof(int));
+      if (2 * ry + 1 > rows_cap) {
+        printf("Could not filter plane %d. Error: vertical kernel of %d taps exceeds the LDS budget\n",
+               imagePlaneIndex, (int)s.ky.size());
+        return false;
+      }
+      if (th + 2 * ry > rows_cap) th = rows_cap - 2 * ry;
+      for (int y = 0; y < s.height; y += th)
+        for (int x = 0; x < s.width; x += kTileW) {
+          LowpassTile t;
+          t.seg = (int)i;
+          t.x0 = L + x;
+          t.y0 = T + y;
+          t.w = std::min(kTileW, s.width - x);
+          t.h = std::min(th, s.height - y);
+          tiles.push_back(t);
+          max_rows = std::max(max_rows, t.h + 2 * ry);
+        }
+    }
+  p.ntiles = (int)tiles.size();
+  p.max_rows = max_rows;
+  p.full_cover = covered == (int64_t)w * h;  // segments of one plane never overlap
+  if (p.ntiles) {
+    if (!p.tiles.reserve(tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(p.tiles.as<void>(), tiles.data(), tiles.size() * sizeof(LowpassTile),
+                              hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)") ||
+        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+      return false;
+  }
+  p.tiles_w = w;
+  p.tiles_h = h;
+  return true;
+}
+
+bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes,
+                                     int in_stride, uint8_t* d_out, int64_t out_frame_bytes,
+                                     int out_stride, int w, int h, int n_frames, int imagePlaneIndex) {
+  if (!ensureTiles(p, w, h, imagePlaneIndex)) return false;
+  if (!p.full_cover) {
+    // Mat::zeros(...) of filterPlane (:625): only visible where no segment writes
+    for (int f = 0; f < n_frames; f++)
+      if (!check(hipMemset2DAsync(d_out + (size_t)f * out_frame_bytes, (size_t)out_stride, 0, (size_t)w,
+                                  (size_t)h, stream_), "hipMemset2DAsync"))
+        return false;
+  }
+  LowpassArgs a;
+  a.src = d_in;
+  a.src_frame_bytes = in_frame_bytes;
+  a.sstride = in_stride;
+  a.dst = d_out;
+  a.dst_frame_bytes = out_frame_bytes;
+  a.dstride = out_stride;
+  a.w = w;
+  a.h = h;
+  a.tiles = p.tiles.as<LowpassTile>();
+  a.ntiles = p.ntiles;
+  a.segs = p.segs.as<SegmentDev>();
+  a.taps_q8 = p.taps_q8.as<int>();
+  a.taps_f32 = p.taps_f32.as<float>();
+  a.max_rows = p.max_rows;
+  a.tile_w = kTileW;
+  return check(launch_lowpass(a, n_frames, stream_), "low-pass launch");
+}
+
+// reference VideoFrameTransform::transformPlane (VideoFrameTransform.cpp:707-794), batched
+bool VideoFrameTransform::runPlane(const uint8_t* d_in, int64_t in_frame_bytes, int in_w, int in_h,
+                                   int in_stride, uint8_t* d_out, int64_t out_frame_bytes, int out_w,
+                                   int out_h, int out_stride, int n_frames, int idx, int imagePlaneIndex) {
+  PlaneState& p = planes_[idx];
+  const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
+  const int interp = (int)ctx_.interpolation_alg;
+  if (!valid_interp(interp)) {
+    // reference :780-783: message, nothing written, still "true"
+    printf("Could not find interpolation algorithm for plane %d", imagePlaneIndex);
+    return true;
+  }
+  if (out_h != p.map_h || out_w != p.map_w) {
+    printf("Could not transform the plane %d. Error: supersampled output (width/height_scale_factor != 1, "
+           "cv::resize INTER_AREA) is not implemented on the HIP path yet\n", imagePlaneIndex);
+    return false;
+  }
+  const uint8_t* src = d_in;
+  int64_t src_frame_bytes = in_frame_bytes;
+  int sstride = in_stride;
+  if (ctx_.enable_low_pass_filter) {
+    const int bstride = (in_w + 255) & ~255;
+    const int64_t plane_bytes = (int64_t)bstride * in_h;
+    if (!blurred_.reserve((size_t)plane_bytes * (size_t)n_frames)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
+    if (!runLowpass(p, d_in, in_frame_bytes, in_stride, blurred_.as<uint8_t>(), plane_bytes, bstride, in_w,
+                    in_h, n_frames, imagePlaneIndex))
+      return false;
+    src = blurred_.as<uint8_t>();
+    src_frame_bytes = plane_bytes;
+    sstride = bstride;
+  }
+  if (idx != 0 && barrel) {  // :743-747
+    if (!check(launch_fill_plane(d_out, out_frame_bytes, out_w, out_h, out_stride, 128, n_frames, stream_),
+               "fill launch"))
+      return false;
+  }
+  GatherArgs a;
+  a.src = src;
+  a.src_frame_bytes = src_frame_bytes;
+  a.sw = in_w;
+  a.sh = in_h;
+  a.sstride = sstride;
+  a.dst = d_out;
+  a.dst_frame_bytes = out_frame_bytes;
+  a.dw = out_w;
+  a.dh = out_h;
+  a.dstride = out_stride;
+  a.lut = p.lut.as<LutEntry>();
+  a.wtab = weights_.as<int16_t>();
+  a.interp = interp;
+  a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
+  return check(launch_remap_gather(a, n_frames, stream_), "remap launch");
+}
+
+// reference VideoFrameTransform::transformFramePlane (VideoFrameTransform.cpp:1319-1351)
+bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outputData, int inputWidth,
+                                              int inputHeight, int inputWidthWithPadding, int outputWidth,
+                                              int outputHeight, int outputWidthWithPadding, int idx,
+                                              int imagePlaneIndex) {
+  if (!ok_) return false;
+  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid) {
+    printf("Could not transform the plane %d. Error: no map generated for index %d\n", imagePlaneIndex, idx);
+    return false;
+  }
+  if (!inputData || !outputData || inputWidth <= 0 || inputHeight <= 0 || outputWidth <= 0 ||
+      outputHeight <= 0 || inputWidthWithPadding < inputWidth || outputWidthWithPadding < outputWidth) {
+    printf("Could not transform the plane %d. Error: invalid buffer description\n", imagePlaneIndex);
+    return false;
+  }
+  DeviceGuard g(device_);
+  const PtrKind ik = classify(inputData), ok = classify(outputData);
+  const size_t in_bytes = (size_t)inputWidthWithPadding * (size_t)(inputHeight - 1) + (size_t)inputWidth;
+  const size_t out_bytes = (size_t)outputWidthWithPadding * (size_t)(outputHeight - 1) + (size_t)outputWidth;
+
+  const uint8_t* d_in = inputData;
+  int in_stride = inputWidthWithPadding;
+  if (ik == PtrKind::Host) {
+    // stage over PCIe: rows packed at a 256-byte aligned pitch
+    in_stride = (inputWidth + 255) & ~255;
+    if (!stage_in_.reserve((size_t)in_stride * inputHeight)) return check(hipErrorOutOfMemory, "hipMalloc(stage_in)");
+    if (!check(hipMemcpy2DAsync(stage_in_.as<void>(), (size_t)in_stride, inputData, (size_t)inputWidthWithPadding,
+                                (size_t)inputWidth, (size_t)inputHeight, hipMemcpyHostToDevice, stream_),
+               "hipMemcpy2DAsync(H2D)"))
+      return false;
+    d_in = stage_in_.as<uint8_t>();
+  }
+  uint8_t* d_out = outputData;
+  int out_stride = outputWidthWithPadding;
+  if (ok == PtrKind::Host) {
+    out_stride = (outputWidth + 255) & ~255;
+    if (!stage_out_.reserve((size_t)out_stride * outputHeight)) return check(hipErrorOutOfMemory, "hipMalloc(stage_out)");
+    d_out = stage_out_.as<uint8_t>();
+    const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
+    if (barrel) {
+      // BORDER_TRANSPARENT leaves destination bytes untouched: start from the caller's content
+      if (!check(hipMemcpy2DAsync(d_out, (size_t)out_stride, outputData, (size_t)outputWidthWithPadding,
+                                  (size_t)outputWidth, (size_t)outputHeight, hipMemcpyHostToDevice, stream_),
+                 "hipMemcpy2DAsync(H2D)"))
+        return false;
+    }
+  }
+  (void)in_bytes;
+  (void)out_bytes;
+  if (!runPlane(d_in, 0, inputWidth, inputHeight, in_stride, d_out, 0, outputWidth, outputHeight, out_stride, 1,
+                idx, imagePlaneIndex))
+    return false;
+  if (ok == PtrKind::Host) {
+    if (!check(hipMemcpy2DAsync(outputData, (size_t)outputWidthWithPadding, d_out, (size_t)out_stride,
+                                (size_t)outputWidth, (size_t)outputHeight, hipMemcpyDeviceToHost, stream_),
+               "hipMemcpy2DAsync(D2H)"))
+      return false;
+  }
+  // the reference call is synchronous: the output is complete when it returns
+  return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+bool VideoFrameTransform::transformFrames(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
+                                          int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes,
+                                          int n_planes) {
+  if (!ok_) return false;
+  if (!d_in || !d_out || n_frames < 0 || !planes || n_planes <= 0) {
+    printf("transform360: T360_transformFrames: invalid arguments\n");
+    return false;
+  }
+  if (n_frames == 0) return true;
+  DeviceGuard g(device_);
+  for (int k = 0; k < n_planes; k++) {
+    const T360PlaneDesc& d = planes[k];
+    if (d.map_index < 0 || d.map_index >= kMaxMaps || !planes_[d.map_index].valid) {
+      printf("Could not transform the plane %d. Error: no map generated for index %d\n", k, d.map_index);
+      return false;
+    }
+    if (d.in_width <= 0 || d.in_height <= 0 || d.out_width <= 0 || d.out_height <= 0 ||
+        d.in_stride < d.in_width || d.out_stride < d.out_width) {
+      printf("Could not transform the plane %d. Error: invalid plane description\n", k);
+      return false;
+    }
+    if (!runPlane(d_in + d.in_offset, in_frame_bytes, d.in_width, d.in_height, d.in_stride, d_out + d.out_offset,
+                  out_frame_bytes, d.out_width, d.out_height, d.out_stride, n_frames, d.map_index, k))
+      return false;
+  }
+  return true;
+}
+
+bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int width, int height, int in_stride,
+                                      int out_stride, int idx) {
+  if (!ok_ || idx < 0 || idx >= kMaxMaps || !planes_[idx].valid) return false;
+  if (!ctx_.enable_low_pass_filter) {
+    printf("transform360: T360_filterPlane: the low-pass filter is disabled in this context\n");
+    return false;
+  }
+  DeviceGuard g(device_);
+  return runLowpass(planes_[idx], d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx);
+}
+
+bool VideoFrameTransform::getMapSize(int idx, int* w, int* h) const {
+  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid) return false;
+  *w = planes_[idx].map_w;
+  *h = planes_[idx].map_h;
+  return true;
+}
+
+bool VideoFrameTransform::copyMap(int idx, float* host_dst) {
+  if (!ok_ || idx < 0 || idx >= kMaxMaps || !planes_[idx].valid || !host_dst) return false;
+  DeviceGuard g(device_);
+  const PlaneState& p = planes_[idx];
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  return check(hipMemcpy(host_dst, p.map.as<void>(), (size_t)p.map_w * p.map_h * sizeof(float2), hipMemcpyDeviceToHost),
+               "hipMemcpy(map)");
+}
+
+int VideoFrameTransform::segmentCount(int idx) const {
+  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid) return 0;
+  return (int)planes_[idx].filter.segments.size();
+}
+
+bool VideoFrameTransform::getSegment(int idx, int i, int* rect4, int* lens2, int* fixed_point) const {
+  if (i < 0 || i >= segmentCount(idx)) return false;
+  const Segment& s = planes_[idx].filter.segments[(size_t)i];
+  rect4[0] = s.left;
+  rect4[1] = s.top;
+  rect4[2] = s.width;
+  rect4[3] = s.height;
+  lens2[0] = (int)s.kx.size();
+  lens2[1] = (int)s.ky.size();
+  if (fixed_point) *fixed_point = s.fixed_point ? 1 : 0;
+  return true;
+}
+
+bool VideoFrameTransform::copySegmentKernels(int idx, int i, float* kx, float* ky) const {
+  if (i < 0 || i >= segmentCount(idx)) return false;
+  const Segment& s = planes_[idx].filter.segments[(size_t)i];
+  memcpy(kx, s.kx.data(), s.kx.size() * sizeof(float));
+  memcpy(ky, s.ky.data(), s.ky.size() * sizeof(float));
+  return true;
+}

@@ -1,0 +1,114 @@
+// t360_transform.h -- the object behind the opaque `VideoFrameTransform*` handle.
+//
+// Mirrors the public surface of the reference class (reference VideoFrameTransform.h:40-160:
+// ctor from FrameTransformContext, generateMapForPlane, transformFramePlane) so the C entry
+// points stay one-line trampolines as in the reference (VideoFrameTransformHandler.cpp:18-64).
+// State redesigned for the GPU: warpMats_ -> device float map + packed sample LUT;
+// filterKernelsX_/Y_ + segmentFilteringConfigs_ -> packed device tap arrays + a tile work list.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "Transform360/t360_device.h"
+#include "t360_filtercfg.h"
+#include "t360_internal.h"
+#include "t360_kernels.h"
+
+namespace t360 {
+
+// hipMalloc'd buffer that only ever grows
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { release(); }
+  bool reserve(size_t bytes);  // contents are NOT preserved on growth
+  void release();
+  template <typename T>
+  T* as() const { return static_cast<T*>(ptr_); }
+  size_t size() const { return bytes_; }
+
+ private:
+  void* ptr_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+// OpenCV's fixed-point 2-D interpolation table for LINEAR / CUBIC / LANCZOS4 (host build).
+bool build_inter_table(int interp, std::vector<int16_t>* tab, int* ksize);
+
+}  // namespace t360
+
+// Global-namespace class: `typedef class VideoFrameTransform VideoFrameTransform;` in
+// Transform360/VideoFrameTransformHandler.h names exactly this type.
+class VideoFrameTransform {
+ public:
+  explicit VideoFrameTransform(const FrameTransformContext* ctx);
+  ~VideoFrameTransform();
+  VideoFrameTransform(const VideoFrameTransform&) = delete;
+  VideoFrameTransform& operator=(const VideoFrameTransform&) = delete;
+
+  bool ok() const { return ok_; }
+
+  // reference VideoFrameTransform::generateMapForPlane (VideoFrameTransform.cpp:504-576)
+  bool generateMapForPlane(int inputWidth, int inputHeight, int outputWidth, int outputHeight,
+                           int transformMatPlaneIndex);
+  // reference VideoFrameTransform::transformFramePlane (VideoFrameTransform.cpp:1319-1351);
+  // buffers may be host or device memory
+  bool transformFramePlane(uint8_t* inputData, uint8_t* outputData, int inputWidth, int inputHeight,
+                           int inputWidthWithPadding, int outputWidth, int outputHeight,
+                           int outputWidthWithPadding, int transformMatPlaneIndex, int imagePlaneIndex);
+
+  // additive (Transform360/t360_device.h)
+  bool setStream(void* hipStream);
+  bool synchronize();
+  bool transformFrames(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
+                       int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes, int n_planes);
+  bool filterPlane(const uint8_t* d_in, uint8_t* d_out, int width, int height, int in_stride,
+                   int out_stride, int map_index);
+  bool getMapSize(int idx, int* w, int* h) const;
+  bool copyMap(int idx, float* host_dst);
+  int segmentCount(int idx) const;
+  bool getSegment(int idx, int i, int* rect4, int* lens2, int* fixed_point) const;
+  bool copySegmentKernels(int idx, int i, float* kx, float* ky) const;
+
+ private:
+  struct PlaneState {
+    bool valid = false;
+    int in_w = 0, in_h = 0, out_w = 0, out_h = 0;  // as given to generateMapForPlane
+    int map_w = 0, map_h = 0;                      // scaled output size
+    t360::DeviceBuffer map;                        // float2[map_h][map_w]
+    t360::DeviceBuffer lut;                        // LutEntry[map_h][map_w]
+    // low-pass
+    t360::FilterConfig filter;
+    t360::DeviceBuffer segs, taps_q8, taps_f32, tiles;
+    int tiles_w = -1, tiles_h = -1;  // plane size the tile list was built for
+    int ntiles = 0, max_rows = 0;
+    bool full_cover = false;
+  };
+
+  bool check(hipError_t e, const char* what) const;
+  bool ensureWeights();
+  bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
+  // all-device core: one plane of n frames
+  bool runPlane(const uint8_t* d_in, int64_t in_frame_bytes, int in_w, int in_h, int in_stride,
+                uint8_t* d_out, int64_t out_frame_bytes, int out_w, int out_h, int out_stride,
+                int n_frames, int idx, int imagePlaneIndex);
+  bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
+                  uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
+                  int imagePlaneIndex);
+
+  FrameTransformContext ctx_;
+  bool ok_ = false;
+  int device_ = 0;
+  hipStream_t own_stream_ = nullptr;
+  hipStream_t stream_ = nullptr;
+  PlaneState planes_[t360::kMaxMaps];
+  t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
+  bool weights_ready_ = false;
+  t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
+  t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
+};
