@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s remapped on the BASELINE.json workload, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config 2|3|1|4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): a synthetic
+stream of 3840x1920 8-bit yuv420p equirect frames -> 512-edge CUBEMAP_32 (1536x1024), bicubic,
+low-pass off.  Frames are counter-hash noise generated on the device and RESIDENT IN HBM before
+the timed region starts; one "step" is one pass of the hot path (all three planes) over one batch
+of F frames (default 32: 354 MB of input, larger than the 256 MB Infinity Cache).
+
+Multi-GPU (--gpus N under torch.distributed.run): whole frames are sharded across ranks --
+rank r owns frames r*F .. r*F+F-1 of every step (weak scaling, no data-path collective).  RCCL
+is used only outside the timed region: broadcast of the 112-byte context from rank 0 and
+all_gather of per-rank output checksums.
+
+Rank 0 prints ONE JSON line:
+  value      = frames/s (whole job) x output luma pixels / 1e6          [Mpix/s]
+  roofline   = algorithmic bytes of the dominant kernel per launch / its average launch duration
+               (HIP events on the launch stream, inside the timed region) vs 8 TB/s HBM peak
+  cpu_baseline = the CPU oracle (restatement of the reference's OpenCV path, NOT linked OpenCV)
+               with the reference's threading structure, timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def workload(config):
+    from transform360_amd.abi import (CUBIC, LANCZOS4, NEAREST, STEREO_FORMAT_TB)
+    if config == 1:
+        return dict(name="cfg1: 1920x960 yuv420p -> 256-edge cubemap, nearest, low-pass off",
+                    in_w=1920, in_h=960, edge=256, ov=dict(interpolation_alg=NEAREST, enable_low_pass_filter=0))
+    if config == 2:
+        return dict(name="cfg2: 3840x1920 yuv420p MONO -> 512-edge cubemap (1536x1024), bicubic, low-pass off",
+                    in_w=3840, in_h=1920, edge=512, ov=dict(interpolation_alg=CUBIC, enable_low_pass_filter=0))
+    if config == 3:
+        return dict(name="cfg3: 3840x1920 yuv420p MONO -> 512-edge cubemap, bicubic + segmented low-pass 32x15",
+                    in_w=3840, in_h=1920, edge=512,
+                    ov=dict(interpolation_alg=CUBIC, enable_low_pass_filter=1, num_horizontal_segments=32,
+                            num_vertical_segments=15, adjust_kernel=1, enable_multi_threading=1))
+    if config == 4:
+        return dict(name="cfg4: 7680x3840 yuv420p TOP_BOTTOM -> 1024-edge cubemap TB (3072x4096), Lanczos4",
+                    in_w=7680, in_h=3840, edge=1024,
+                    ov=dict(interpolation_alg=LANCZOS4, enable_low_pass_filter=0,
+                            input_stereo_format=STEREO_FORMAT_TB, output_stereo_format=STEREO_FORMAT_TB))
+    raise SystemExit("unknown --config %r" % config)
+
+
+def cpu_baseline(wl, lin, lout, budget_s):
+    """The oracle on the host cores: remap in row stripes over T threads, low-pass one task per
+    segment (the reference's structure), planes sequentially (vf_transform360.c:368-397)."""
+    import numpy as np
+
+    from oracle import t360_oracle as O
+    from transform360_amd.abi import filter_defaults
+    from transform360_amd.handler import frame_seed, noise_bytes
+    T = os.cpu_count() or 1
+    ctx = filter_defaults(**wl["ov"])
+    o = O.Oracle(ctx, threads=T)
+    t0 = time.perf_counter()
+    for idx, k in ((0, 0), (1, 1)):
+        assert o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+    init_s = time.perf_counter() - t0
+    frame = noise_bytes(lin.frame_bytes, frame_seed(0))
+    outs = [np.zeros((h, w), np.uint8) for (w, h) in lout.dims]
+
+    def one_frame():
+        for p in range(3):
+            assert o.transformFramePlane(lin.plane_view(frame, p), outs[p], 1 if p else 0, p)
+
+    one_frame()  # warm (tables, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one_frame()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    fps = n / el
+    o1 = O.Oracle(ctx, threads=1)
+    for idx, k in ((0, 0), (1, 1)):
+        assert o1.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+    t0 = time.perf_counter()
+    for p in range(3):
+        assert o1.transformFramePlane(lin.plane_view(frame, p), outs[p], 1 if p else 0, p)
+    fps1 = 1.0 / (time.perf_counter() - t0)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    mpix = lout.dims[0][0] * lout.dims[0][1] / 1e6
+    return {
+        "value": round(fps * mpix, 3), "unit": "Mpix/s", "cores": T, "kind": "port",
+        "sample": "%d frames of the same workload in %.1f s on %d threads (oracle = restatement of the "
+                  "reference's OpenCV path, not linked OpenCV); 1 thread: %.3f Mpix/s; map init %.2f s"
+                  % (n, el, T, fps1 * mpix, init_s),
+        "cpu_model": model, "fps": round(fps, 3), "value_1thread": round(fps1 * mpix, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from transform360_amd import handler
+    from transform360_amd.abi import FrameTransformContext, config_output, filter_defaults
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the remap path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    wl = workload(args.config)
+    in_w, in_h = wl["in_w"], wl["in_h"]
+    ctx = filter_defaults(**wl["ov"])
+    out_w, out_h = config_output(in_w, in_h, wl["edge"], ctx.output_layout, ctx.input_stereo_format,
+                                 ctx.output_stereo_format)
+    if dist is not None:
+        # init state: rank 0's 112-byte context is broadcast over RCCL; every rank rebuilds maps from it
+        buf = torch.frombuffer(bytearray(bytes(ctx)), dtype=torch.uint8).cuda()
+        dist.broadcast(buf, src=0)
+        ctx = FrameTransformContext.from_buffer_copy(bytes(buf.cpu().numpy()))
+
+    lin = handler.FrameLayout(in_w, in_h)
+    lout = handler.FrameLayout(out_w, out_h)
+    F = args.frames
+    stream = torch.cuda.current_stream()
+
+    t_init0 = time.perf_counter()
+    t = handler.VideoFrameTransform(ctx)
+    for idx, k in ((0, 0), (1, 1)):
+        assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+    assert t.setStream(stream)
+    init_ms = (time.perf_counter() - t_init0) * 1e3
+
+    # synthetic stream: this rank's frames of one step, resident in HBM
+    d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+    for j in range(F):
+        handler.fill_noise(d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], handler.frame_seed(rank * F + j))
+    d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
+    descs = t.plane_descs(lin, lout)
+    luma_desc = (type(descs[0]) * 1)(descs[0])
+    chroma_desc = (type(descs[0]) * 2)(descs[1], descs[2])
+
+    def step(timed_events=None):
+        if timed_events is not None:
+            e0, e1 = timed_events
+            e0.record(stream)
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, F, luma_desc)
+        if timed_events is not None:
+            e1.record(stream)
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, F, chroma_desc)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    luma_ms = [a.elapsed_time(b) for a, b in events]
+
+    # verification outside the timed region: per-rank checksum of the outputs, gathered on rank 0
+    csum = torch.sum(d_out.view(-1).to(torch.int64)).reshape(1)
+    if dist is not None:
+        allc = [torch.zeros_like(csum) for _ in range(world)]
+        dist.all_gather(allc, csum)
+        checksums = [int(c.item()) for c in allc]
+    else:
+        checksums = [int(csum.item())]
+
+    if rank == 0:
+        frames_total = args.steps * F * world
+        fps = frames_total / elapsed
+        out_mpix = out_w * out_h / 1e6
+        alg_frame = lin.payload_bytes() + lout.payload_bytes()
+        luma_alg = F * (in_w * in_h + out_w * out_h)
+        luma_avg_s = (sum(luma_ms) / len(luma_ms)) * 1e-3
+        traffic = None
+        if os.path.exists(args.traffic_file):
+            try:
+                with open(args.traffic_file) as f:
+                    tj = json.load(f)
+                if tj.get("config") == args.config and tj.get("frames") == F:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        res = {
+            "metric": "Mpix/s remapped (4K equirect->512-edge cubemap, bicubic)" if args.config == 2
+                      else "Mpix/s remapped (%s)" % wl["name"],
+            "value": round(fps * out_mpix, 1), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["name"], "frames_per_step_per_gpu": F, "pixel_format": "yuv420p 8-bit",
+                       "in": "%dx%d" % (in_w, in_h), "out": "%dx%d" % (out_w, out_h),
+                       "sharding": "whole frames per rank, no data-path collective", "input": "resident in HBM"},
+            "fps": round(fps, 1),
+            "frac_of_hbm_roofline_whole_job": round(alg_frame * fps / (HBM_PEAK_BPS * world), 4),
+            "roofline": {
+                "bound": "hbm", "kernel": "remap gather, luma plane of %d frames per launch" % F,
+                "achieved": round(luma_alg / luma_avg_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                "frac": round(luma_alg / luma_avg_s / HBM_PEAK_BPS, 4),
+                "algorithmic_bytes_per_launch": luma_alg, "avg_launch_ms": round(luma_avg_s * 1e3, 4),
+                "traffic": traffic,
+            },
+            "init_ms": round(init_ms, 1),
+            "output_checksums": checksums,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)
+        print(json.dumps(res))
+    t.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,10 +42,12 @@ const char* T360_version(void);
 /* Number of visible HIP devices (0 if the runtime cannot be initialised). */
 int T360_deviceCount(void);
 
-/* Use `hip_stream` (a hipStream_t) for all device work of this handle; NULL restores the
- * handle's own stream.  Device-pointer calls of the reference ABI still synchronise before
- * returning; the batch calls below do not. */
+/* Use `hip_stream` (a hipStream_t) for all device work of this handle.  NULL means HIP's NULL
+ * (legacy default) stream, as everywhere in the HIP API.  A new handle starts on a private
+ * non-blocking stream; T360_useOwnStream returns to it.  Device-pointer calls of the reference
+ * ABI still synchronise before returning; the batch calls below do not. */
 int T360_setStream(VideoFrameTransform* transform, void* hip_stream);
+int T360_useOwnStream(VideoFrameTransform* transform);
 
 /* Block until everything queued on the handle's stream has finished. */
 int T360_synchronize(VideoFrameTransform* transform);

@@ -13,6 +13,7 @@
  * pool (the reference creates one thread per segment per call).
  */
 #include <pthread.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -120,20 +121,66 @@ static void* job_worker(void* a) {
   return NULL;
 }
 
+/* Persistent worker pool (OpenCV's parallel_for_ also keeps its workers alive between calls).
+ * One job at a time; callers are serialised by run_mu. */
+#define T360O_MAX_WORKERS 512
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+  pthread_mutex_t run_mu;
+  pthread_t th[T360O_MAX_WORKERS];
+  int nworkers;
+  Job* job;
+  unsigned generation;
+  int want;    /* workers with id < want take part in the current job */
+  int pending; /* participants that have not finished yet */
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+            PTHREAD_MUTEX_INITIALIZER, {0}, 0, NULL, 0, 0, 0};
+
+static void* pool_worker(void* a) {
+  const int id = (int)(intptr_t)a;
+  unsigned seen = 0;
+  pthread_mutex_lock(&g_pool.mu);
+  for (;;) {
+    while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+    seen = g_pool.generation;
+    if (id >= g_pool.want) continue;
+    Job* j = g_pool.job;
+    pthread_mutex_unlock(&g_pool.mu);
+    job_worker(j);
+    pthread_mutex_lock(&g_pool.mu);
+    if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+  }
+  return NULL;
+}
+
 static void run_tasks(int threads, int ntasks, void (*fn)(void*, int), void* arg) {
   Job j = {fn, arg, ntasks, 0};
   if (threads <= 1 || ntasks <= 1) {
     job_worker(&j);
     return;
   }
-  int n = threads < ntasks ? threads : ntasks;
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n);
-  int started = 0;
-  for (int i = 0; i < n - 1; i++)
-    if (pthread_create(&th[started], NULL, job_worker, &j) == 0) started++;
+  int helpers = (threads < ntasks ? threads : ntasks) - 1; /* the caller works too */
+  if (helpers > T360O_MAX_WORKERS) helpers = T360O_MAX_WORKERS;
+  pthread_mutex_lock(&g_pool.run_mu);
+  pthread_mutex_lock(&g_pool.mu);
+  while (g_pool.nworkers < helpers) {
+    if (pthread_create(&g_pool.th[g_pool.nworkers], NULL, pool_worker, (void*)(intptr_t)g_pool.nworkers) != 0) break;
+    pthread_detach(g_pool.th[g_pool.nworkers]);
+    g_pool.nworkers++;
+  }
+  if (helpers > g_pool.nworkers) helpers = g_pool.nworkers;
+  g_pool.job = &j;
+  g_pool.want = helpers;
+  g_pool.pending = helpers;
+  g_pool.generation++;
+  pthread_cond_broadcast(&g_pool.cv_work);
+  pthread_mutex_unlock(&g_pool.mu);
   job_worker(&j);
-  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
-  free(th);
+  pthread_mutex_lock(&g_pool.mu);
+  while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+  pthread_mutex_unlock(&g_pool.mu);
+  pthread_mutex_unlock(&g_pool.run_mu);
 }
 
 /* ---- low-pass ---- */

@@ -21,7 +21,7 @@ REFERENCE_SYMBOLS = (
     "VideoFrameTransform_transformFramePlane",
 )
 ADDITIVE_SYMBOLS = (
-    "T360_version", "T360_deviceCount", "T360_setStream", "T360_synchronize", "T360_transformFrames",
+    "T360_version", "T360_deviceCount", "T360_setStream", "T360_useOwnStream", "T360_synchronize", "T360_transformFrames",
     "T360_filterPlane", "T360_getMapSize", "T360_copyMap", "T360_getSegmentCount", "T360_getSegment",
     "T360_copySegmentKernels", "T360_fillNoise",
 )
@@ -80,6 +80,7 @@ def load():
     L.T360_deviceCount.restype = i
     L.T360_setStream.argtypes = [vp, vp]
     L.T360_synchronize.argtypes = [vp]
+    L.T360_useOwnStream.argtypes = [vp]
     L.T360_transformFrames.argtypes = [vp, u8p, C.c_int64, u8p, C.c_int64, i, C.POINTER(T360PlaneDesc), i]
     L.T360_filterPlane.argtypes = [vp, u8p, u8p, i, i, i, i, i]
     L.T360_getMapSize.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]

@@ -93,6 +93,11 @@ T360_EXPORT int T360_setStream(VideoFrameTransform* t, void* s) {
   return guarded("T360_setStream", [&] { return t->setStream(s); });
 }
 
+T360_EXPORT int T360_useOwnStream(VideoFrameTransform* t) {
+  if (!t) return 0;
+  return guarded("T360_useOwnStream", [&] { return t->useOwnStream(); });
+}
+
 T360_EXPORT int T360_synchronize(VideoFrameTransform* t) {
   if (!t) return 0;
   return guarded("T360_synchronize", [&] { return t->synchronize(); });

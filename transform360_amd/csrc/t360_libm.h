@@ -51,20 +51,12 @@ T360_HD float fabs_(float x) { return bits2f(f2bits(x) & 0x7fffffffu); }
 
 // correctly rounded square root / division, spelled so the device compiler cannot pick an
 // approximate expansion
-T360_HD float sqrt_rn(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(x);
-#else
-  return __builtin_sqrtf(x);
-#endif
-}
-T360_HD float div_rn(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fdiv_rn(a, b);
-#else
-  return a / b;
-#endif
-}
+// NOTE: HIP's __fsqrt_rn() maps to the approximate native sqrt unless OCML_BASIC_ROUNDED_OPERATIONS
+// is defined (measured: 4 % of map coordinates off by one ulp).  The plain builtin / operator are
+// lowered by hipcc to the IEEE sequences (v_sqrt_f32 + fma correction, v_div_scale/fmas/fixup)
+// because -fhip-fp32-correctly-rounded-divide-sqrt is the default.
+T360_HD float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+T360_HD float div_rn(float a, float b) { return a / b; }
 
 // ---- atanf: argument reduction to |x| < 7/16 around 0.5, 1, 1.5, inf; odd/even split polynomial
 T360_HD float atan_f32(float x) {

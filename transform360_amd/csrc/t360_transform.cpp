@@ -194,7 +194,14 @@ bool VideoFrameTransform::check(hipError_t e, const char* what) const {
 bool VideoFrameTransform::setStream(void* s) {
   DeviceGuard g(device_);
   if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
-  stream_ = s ? static_cast<hipStream_t>(s) : own_stream_;
+  stream_ = static_cast<hipStream_t>(s);  // nullptr = HIP's NULL stream
+  return true;
+}
+
+bool VideoFrameTransform::useOwnStream() {
+  DeviceGuard g(device_);
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  stream_ = own_stream_;
   return true;
 }
 
@@ -206,7 +213,9 @@ bool VideoFrameTransform::synchronize() {
 bool VideoFrameTransform::ensureWeights() {
   if (weights_ready_) return true;
   const int interp = (int)ctx_.interpolation_alg;
-  if (interp == NEAREST) {
+  if (interp == NEAREST || !valid_interp(interp)) {
+    // NEAREST needs no table; an unknown code never reaches the gather (runPlane prints and
+    // returns true like the reference's default: branch)
     weights_ready_ = true;
     return true;
   }

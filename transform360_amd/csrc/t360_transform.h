@@ -64,6 +64,7 @@ class VideoFrameTransform {
 
   // additive (Transform360/t360_device.h)
   bool setStream(void* hipStream);
+  bool useOwnStream();
   bool synchronize();
   bool transformFrames(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
                        int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes, int n_planes);

@@ -97,9 +97,13 @@ class VideoFrameTransform:
 
     # ---- additive surface (include/Transform360/t360_device.h) ----
     def setStream(self, stream):
-        """stream: torch.cuda.Stream, raw hipStream_t integer, or None for the handle's own."""
+        """stream: torch.cuda.Stream or raw hipStream_t integer (0 / None = HIP's NULL stream,
+        which is what torch's default current stream is)."""
         raw = getattr(stream, "cuda_stream", stream)
         return bool(self._l.T360_setStream(self._h, raw or None))
+
+    def useOwnStream(self):
+        return bool(self._l.T360_useOwnStream(self._h))
 
     def synchronize(self):
         return bool(self._l.T360_synchronize(self._h))
