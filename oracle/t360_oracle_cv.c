@@ -15,6 +15,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -98,6 +99,7 @@ static int16_t g_tab_linear[INTER_TAB_SIZE2 * 4];
 static int16_t g_tab_cubic[INTER_TAB_SIZE2 * 16];
 static int16_t g_tab_lanczos[INTER_TAB_SIZE2 * 64];
 static int g_tab_ready[5];
+static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static void build_tab(int interp, int16_t* itab_base, int ksize) {
   float tab1[8 * INTER_TAB_SIZE];
@@ -151,10 +153,14 @@ const int16_t* t360o_inter_tab(int interp, int* ksize) {
     case LANCZOS4: tab = g_tab_lanczos; ks = 8; break;
     default: return NULL;
   }
-  if (!g_tab_ready[interp]) {
-    build_tab(interp, tab, ks);
-    __sync_synchronize();
-    g_tab_ready[interp] = 1;
+  if (!__atomic_load_n(&g_tab_ready[interp], __ATOMIC_ACQUIRE)) {
+    /* remap stripes run on several threads: build each table exactly once */
+    pthread_mutex_lock(&g_tab_mu);
+    if (!g_tab_ready[interp]) {
+      build_tab(interp, tab, ks);
+      __atomic_store_n(&g_tab_ready[interp], 1, __ATOMIC_RELEASE);
+    }
+    pthread_mutex_unlock(&g_tab_mu);
   }
   if (ksize) *ksize = ks;
   return tab;

@@ -68,4 +68,42 @@ struct LowpassTile {
   int x0, y0, w, h;  // absolute plane coordinates (stereo eye offset already applied)
 };
 
+// ---- LDS-tiled gather (t360_remap_tiled.hip) ----
+// Tile kinds of the work list.
+enum : int {
+  kTileStaged32 = 0,  // 32x32 output px, 4 px per lane, source box staged through LDS
+  kTileStaged16 = 1,  // 16x16 output px, 1 px per lane, source box staged through LDS
+  kTileDirect16 = 2,  // 16x16 output px, gathers straight from global memory (box too large)
+};
+enum : int {
+  kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
+  kTileSeamShift = 2,  // box x coordinates use (x >= W/2 ? x - W : x)
+};
+
+constexpr int kStageChunk = 16;                 // bytes per staged chunk (one dwordx4 per lane)
+constexpr int kStageChunksPerLane = 4;          // max chunks a lane fetches per frame
+constexpr int kStageMaxBytes = 256 * kStageChunksPerLane * kStageChunk;  // 16 KiB box per tile
+constexpr int kStageMaxCols = 1024;             // 10-bit box column in the tile LUT word
+constexpr int kStageMaxRows = 256;              // 8-bit box row
+
+// One unit of gather work.
+struct __attribute__((aligned(16))) TileDesc {
+  int16_t ox, oy;     // output origin
+  int16_t kind;       // kTile*
+  int16_t flags;      // kTilePartial | kTileSeamShift
+  int32_t x0, y0;     // source box origin incl. stencil halo; x0 is a multiple of 16 (may be < 0)
+  int16_t cpr;        // 16-byte chunks per box row (row pitch in LDS = cpr * 16 bytes)
+  int16_t rows;       // box rows
+  int32_t tlut;       // first word of this tile in the box-relative LUT
+  int32_t pad[2];
+};
+static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
+
+// Bicubic weights re-packed for v_dot4: per phase 12 dwords
+//   [0..3]  high bytes (signed)  of the 4 taps of rows 0..3:  w >> 8
+//   [4..7]  low bytes (unsigned) of the 4 taps of rows 0..3:  w & 255
+//   [8]     rounding + bias constant: 16384 + 128*256*SUM(w >> 8)   (pixels are fed as p-128)
+//   [9..11] padding
+constexpr int kCubicPackDwords = 12;
+
 }  // namespace t360

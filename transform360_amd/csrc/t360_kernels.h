@@ -30,6 +30,33 @@ hipError_t launch_remap_gather(const GatherArgs& a, int nframes, hipStream_t str
 hipError_t launch_fill_plane(uint8_t* dst, int64_t frame_bytes, int w, int h, int stride, int value,
                              int nframes, hipStream_t stream);
 
+// ---- tile planning (t360_tiles.hip) ----
+// out: 30 ints per 32x32 macro tile (5 boxes x {minx, maxx, minx_shifted, maxx_shifted, miny, maxy})
+hipError_t launch_tile_scan(const LutEntry* lut, int dw, int dh, int sw, int* out, hipStream_t stream);
+hipError_t launch_tile_lut(const LutEntry* lut, int dw, int dh, int sw, const TileDesc* tiles, int ntiles,
+                           int halo, uint32_t* tlut, hipStream_t stream);
+
+// ---- LDS-tiled bicubic gather (t360_remap_tiled.hip) ----
+struct TiledArgs {
+  const uint8_t* src;
+  int64_t src_frame_bytes;
+  int sw, sh, sstride;
+  uint8_t* dst;
+  int64_t dst_frame_bytes;
+  int dw, dh, dstride;
+  const TileDesc* tiles;
+  int ntiles;
+  const uint32_t* tlut;     // box-relative LUT words
+  const LutEntry* lut;      // absolute LUT (direct tiles)
+  const int16_t* wtab;      // OpenCV Q15 table (direct tiles)
+  const uint32_t* wpack;    // kCubicPackDwords per phase (staged tiles)
+  int nframes;
+  int frames_per_block;
+  int src_vec_ok;           // plane base and stride are 16-byte aligned: dwordx4 chunk loads
+  int dst_dword_ok;         // plane base and stride are 4-byte aligned: dword stores
+};
+hipError_t launch_remap_tiled_cubic(const TiledArgs& a, hipStream_t stream);
+
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {
   const uint8_t* src;

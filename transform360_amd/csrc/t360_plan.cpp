@@ -1,0 +1,151 @@
+// t360_plan.cpp -- init-time planning of the LDS-tiled gather (host side).
+//
+// From the scanned per-tile bounding boxes (tile_scan_kernel) build the tile work list:
+//   32x32 output tile  -> staged through LDS when its source box (incl. stencil halo, x aligned
+//                         down to 16 bytes) fits the per-workgroup staging budget;
+//   otherwise its four 16x16 quadrants, each staged if it fits, else gathered directly
+//                         (the few tiles touching a pole span a full quadrant of longitudes,
+//                         SURVEY.md 7 H4).
+// Tiles are emitted in output raster order; the kernel hands contiguous ranges to each XCD.
+#include "t360_plan.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace t360 {
+
+namespace {
+
+struct Box {
+  int x0, cpr, y0, rows;
+  bool seam_shift;
+  bool empty;
+  bool fits;
+};
+
+// b: {minx, maxx, minx_shifted, maxx_shifted, miny, maxy} of pixel-centre taps
+Box make_box(const int* b, int halo_lo, int halo_hi) {
+  Box r{};
+  r.empty = b[0] > b[1];
+  if (r.empty) return r;
+  const int w_raw = b[1] - b[0], w_shift = b[3] - b[2];
+  r.seam_shift = w_shift < w_raw;
+  const int xmin = (r.seam_shift ? b[2] : b[0]) - halo_lo;
+  const int xmax = (r.seam_shift ? b[3] : b[1]) + halo_hi;
+  r.x0 = xmin & ~(kStageChunk - 1);  // two's complement: floors negatives too
+  r.cpr = (xmax - r.x0) / kStageChunk + 1;
+  r.y0 = b[4] - halo_lo;
+  r.rows = (b[5] + halo_hi) - r.y0 + 1;
+  r.fits = r.cpr * kStageChunk <= kStageMaxCols && r.rows <= kStageMaxRows &&
+           r.cpr * r.rows <= 256 * kStageChunksPerLane;
+  return r;
+}
+
+}  // namespace
+
+bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, hipStream_t stream,
+                       GatherPlan* plan) {
+  plan->valid = false;
+  plan->ntiles = 0;
+  if (ksize != 4) return true;  // only the bicubic kernel is tiled in this round
+  const int halo_lo = ksize / 2 - 1, halo_hi = ksize / 2;
+  const int tiles_x = (dw + 31) / 32, tiles_y = (dh + 31) / 32;
+  const size_t nmacro = (size_t)tiles_x * tiles_y;
+
+  DeviceBuffer scan;
+  if (!scan.reserve(nmacro * 30 * sizeof(int))) return false;
+  if (launch_tile_scan(d_lut, dw, dh, sw, scan.as<int>(), stream) != hipSuccess) return false;
+  std::vector<int> boxes(nmacro * 30);
+  if (hipMemcpyAsync(boxes.data(), scan.as<void>(), boxes.size() * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
+    return false;
+  if (hipStreamSynchronize(stream) != hipSuccess) return false;
+
+  std::vector<TileDesc> tiles;
+  tiles.reserve(nmacro);
+  int64_t tlut_words = 0, staged_bytes = 0;
+  int n32 = 0, n16 = 0, ndirect = 0;
+  for (int ty = 0; ty < tiles_y; ty++)
+    for (int tx = 0; tx < tiles_x; tx++) {
+      const int* b = &boxes[((size_t)ty * tiles_x + tx) * 30];
+      const Box big = make_box(b, halo_lo, halo_hi);
+      if (big.empty) continue;
+      const int ox = tx * 32, oy = ty * 32;
+      auto emit = [&](const Box& bx, int kind, int tox, int toy, int edge) {
+        TileDesc t{};
+        t.ox = (int16_t)tox;
+        t.oy = (int16_t)toy;
+        t.kind = (int16_t)kind;
+        t.flags = (int16_t)((bx.seam_shift ? kTileSeamShift : 0) |
+                            ((tox + edge > dw || toy + edge > dh) ? kTilePartial : 0));
+        t.x0 = bx.x0;
+        t.y0 = bx.y0;
+        t.cpr = (int16_t)bx.cpr;
+        t.rows = (int16_t)bx.rows;
+        t.tlut = (int32_t)tlut_words;
+        if (kind == kTileStaged32) tlut_words += 1024, n32++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
+        else if (kind == kTileStaged16) tlut_words += 256, n16++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
+        else ndirect++;
+        tiles.push_back(t);
+      };
+      if (big.fits) {
+        emit(big, kTileStaged32, ox, oy, 32);
+        continue;
+      }
+      for (int qd = 0; qd < 4; qd++) {
+        const Box sub = make_box(b + 6 * (1 + qd), halo_lo, halo_hi);
+        if (sub.empty) continue;
+        emit(sub, sub.fits ? kTileStaged16 : kTileDirect16, ox + (qd & 1) * 16, oy + (qd >> 1) * 16, 16);
+      }
+    }
+  if (tiles.size() > 0x7fffffff || tlut_words > 0x7fffffff) return false;
+
+  if (!plan->tiles.reserve(tiles.size() * sizeof(TileDesc)) ||
+      !plan->tlut.reserve((size_t)(tlut_words > 0 ? tlut_words : 1) * sizeof(uint32_t)))
+    return false;
+  if (hipMemcpyAsync(plan->tiles.as<void>(), tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
+                     stream) != hipSuccess)
+    return false;
+  if (launch_tile_lut(d_lut, dw, dh, sw, plan->tiles.as<TileDesc>(), (int)tiles.size(), halo_lo,
+                      plan->tlut.as<uint32_t>(), stream) != hipSuccess)
+    return false;
+  if (hipStreamSynchronize(stream) != hipSuccess) return false;
+  plan->ntiles = (int)tiles.size();
+  plan->n32 = n32;
+  plan->n16 = n16;
+  plan->ndirect = ndirect;
+  plan->staged_bytes = staged_bytes;
+  plan->valid = true;
+  if (getenv("T360_VERBOSE"))
+    printf("transform360: gather plan %dx%d <- %dx%d: %d tiles (%d staged 32x32, %d staged 16x16, %d direct), "
+           "%.2f MB staged per plane (%.2fx the source plane)\n",
+           dw, dh, sw, sh, plan->ntiles, n32, n16, ndirect, staged_bytes / 1e6, (double)staged_bytes / ((double)sw * sh));
+  return true;
+}
+
+// Re-pack OpenCV's Q15 bicubic table for v_dot4 (layout: t360_internal.h kCubicPackDwords)
+void pack_cubic_weights(const std::vector<int16_t>& tab, std::vector<uint32_t>* out) {
+  const int phases = kInterTabSize * kInterTabSize;
+  out->assign((size_t)phases * kCubicPackDwords, 0);
+  for (int f = 0; f < phases; f++) {
+    const int16_t* w = &tab[(size_t)f * 16];
+    uint32_t* o = &(*out)[(size_t)f * kCubicPackDwords];
+    int sum_hi = 0;
+    for (int r = 0; r < 4; r++) {
+      uint32_t hi = 0, lo = 0;
+      for (int c = 0; c < 4; c++) {
+        const int v = w[r * 4 + c];
+        const int h = v >> 8;   // arithmetic shift: floor, in [-128, 127]
+        const int l = v & 255;  // v == h * 256 + l
+        sum_hi += h;
+        hi |= (uint32_t)(h & 255) << (8 * c);
+        lo |= (uint32_t)l << (8 * c);
+      }
+      o[r] = hi;
+      o[4 + r] = lo;
+    }
+    o[8] = (uint32_t)((1 << (kCoefBits - 1)) + 128 * 256 * sum_hi);
+  }
+}
+
+}  // namespace t360

@@ -1,0 +1,28 @@
+// t360_plan.h -- tile work list of the LDS-tiled gather for one map (see t360_plan.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "t360_internal.h"
+#include "t360_kernels.h"
+#include "t360_devbuf.h"
+
+namespace t360 {
+
+struct GatherPlan {
+  bool valid = false;
+  int ntiles = 0, n32 = 0, n16 = 0, ndirect = 0;
+  int64_t staged_bytes = 0;  // sum of staged box bytes over the plane (L2 -> LDS traffic per frame)
+  DeviceBuffer tiles;        // TileDesc[ntiles]
+  DeviceBuffer tlut;         // box-relative LUT words
+};
+
+// d_lut: absolute LUT of the map (dw x dh entries), source plane sw x sh, ksize = taps per axis.
+bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, hipStream_t stream,
+                       GatherPlan* plan);
+
+void pack_cubic_weights(const std::vector<int16_t>& q15_table, std::vector<uint32_t>* out);
+
+}  // namespace t360

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace t360;
@@ -174,6 +175,10 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     return;
   }
   stream_ = own_stream_;
+  if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4096) frames_per_block_ = v;
+  }
   ok_ = true;
 }
 
@@ -226,6 +231,14 @@ bool VideoFrameTransform::ensureWeights() {
   if (!check(hipMemcpy(weights_.as<void>(), tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice),
              "hipMemcpy(weights)"))
     return false;
+  if (interp == CUBIC) {
+    std::vector<uint32_t> pack;
+    pack_cubic_weights(tab, &pack);
+    if (!weights_pack_.reserve(pack.size() * sizeof(uint32_t))) return check(hipErrorOutOfMemory, "hipMalloc(weights)");
+    if (!check(hipMemcpy(weights_pack_.as<void>(), pack.data(), pack.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+               "hipMemcpy(weights)"))
+      return false;
+  }
   weights_ready_ = true;
   return true;
 }
@@ -315,6 +328,15 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     return check(hipErrorOutOfMemory, "hipMalloc(map)");
   if (!check(launch_mapgen(P, p.map.as<float2>(), p.lut.as<LutEntry>(), stream_), "mapgen launch")) return false;
   if (!ensureWeights()) return false;
+  {
+    // tile work list of the LDS-tiled gather (bicubic + BORDER_WRAP only in this round)
+    const bool barrel = olay == LAYOUT_BARREL || olay == LAYOUT_BARREL_SPLIT;
+    p.plan.valid = false;
+    if (P.interp == CUBIC && !barrel && !getenv("T360_NO_TILED")) {
+      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, 4, stream_, &p.plan))
+        return check(hipErrorUnknown, "gather plan");
+    }
+  }
 
   p.in_w = inputWidth;
   p.in_h = inputHeight;
@@ -495,6 +517,33 @@ bool VideoFrameTransform::runPlane(const uint8_t* d_in, int64_t in_frame_bytes, 
     if (!check(launch_fill_plane(d_out, out_frame_bytes, out_w, out_h, out_stride, 128, n_frames, stream_),
                "fill launch"))
       return false;
+  }
+  if (p.plan.valid && interp == CUBIC && !barrel && in_w == p.in_w && in_h == p.in_h) {
+    TiledArgs ta;
+    ta.src = src;
+    ta.src_frame_bytes = src_frame_bytes;
+    ta.sw = in_w;
+    ta.sh = in_h;
+    ta.sstride = sstride;
+    ta.dst = d_out;
+    ta.dst_frame_bytes = out_frame_bytes;
+    ta.dw = out_w;
+    ta.dh = out_h;
+    ta.dstride = out_stride;
+    ta.tiles = p.plan.tiles.as<TileDesc>();
+    ta.ntiles = p.plan.ntiles;
+    ta.tlut = p.plan.tlut.as<uint32_t>();
+    ta.lut = p.lut.as<LutEntry>();
+    ta.wtab = weights_.as<int16_t>();
+    ta.wpack = weights_pack_.as<uint32_t>();
+    ta.nframes = n_frames;
+    ta.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
+    const bool multi = n_frames > 1;
+    ta.src_vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (sstride & 15) == 0 &&
+                    (!multi || (src_frame_bytes & 15) == 0);
+    ta.dst_dword_ok = (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && (out_stride & 3) == 0 &&
+                      (!multi || (out_frame_bytes & 3) == 0);
+    return check(launch_remap_tiled_cubic(ta, stream_), "tiled remap launch");
   }
   GatherArgs a;
   a.src = src;

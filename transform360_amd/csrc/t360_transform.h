@@ -15,27 +15,11 @@
 #include "Transform360/t360_device.h"
 #include "t360_filtercfg.h"
 #include "t360_internal.h"
+#include "t360_devbuf.h"
 #include "t360_kernels.h"
+#include "t360_plan.h"
 
 namespace t360 {
-
-// hipMalloc'd buffer that only ever grows
-class DeviceBuffer {
- public:
-  DeviceBuffer() = default;
-  DeviceBuffer(const DeviceBuffer&) = delete;
-  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-  ~DeviceBuffer() { release(); }
-  bool reserve(size_t bytes);  // contents are NOT preserved on growth
-  void release();
-  template <typename T>
-  T* as() const { return static_cast<T*>(ptr_); }
-  size_t size() const { return bytes_; }
-
- private:
-  void* ptr_ = nullptr;
-  size_t bytes_ = 0;
-};
 
 // OpenCV's fixed-point 2-D interpolation table for LINEAR / CUBIC / LANCZOS4 (host build).
 bool build_inter_table(int interp, std::vector<int16_t>* tab, int* ksize);
@@ -89,6 +73,8 @@ class VideoFrameTransform {
     int tiles_w = -1, tiles_h = -1;  // plane size the tile list was built for
     int ntiles = 0, max_rows = 0;
     bool full_cover = false;
+    // LDS-tiled gather
+    t360::GatherPlan plan;
   };
 
   bool check(hipError_t e, const char* what) const;
@@ -109,7 +95,9 @@ class VideoFrameTransform {
   hipStream_t stream_ = nullptr;
   PlaneState planes_[t360::kMaxMaps];
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
+  t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
+  int frames_per_block_ = 8;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
 };
