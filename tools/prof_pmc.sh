@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/prof_pmc.sh -- rocprofv3 PMC passes for bench.py (run on the GPU box via gpurun).
+# Counters are collected in separate passes (SQ: 8 slots, TCC: FETCH_SIZE costs 3, WRITE_SIZE 2;
+# MI355X_MICROARCH.md "rocprofv3 PMC slots"), each with --kernel-trace only.
+# usage: tools/prof_pmc.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+pass() { # name counters...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
+      python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
+}
+BENCH_ARGS=("$@")
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_ANY
+pass sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR
+pass tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
+pass tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+python "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"

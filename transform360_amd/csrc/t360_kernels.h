@@ -37,25 +37,36 @@ hipError_t launch_tile_lut(const LutEntry* lut, int dw, int dh, int sw, const Ti
                            int halo, uint32_t* tlut, hipStream_t stream);
 
 // ---- LDS-tiled bicubic gather (t360_remap_tiled.hip) ----
-struct TiledArgs {
-  const uint8_t* src;
-  int64_t src_frame_bytes;
-  int sw, sh, sstride;
+struct TiledPlane {
+  const uint8_t* src;       // plane base of frame 0
+  int64_t src_frame_bytes;  // distance between consecutive frames of this plane
   uint8_t* dst;
   int64_t dst_frame_bytes;
+  int sw, sh, sstride;
   int dw, dh, dstride;
   const TileDesc* tiles;
-  int ntiles;
   const uint32_t* tlut;     // box-relative LUT words
   const LutEntry* lut;      // absolute LUT (direct tiles)
+  int ntiles;
+  int dst_dword_ok;         // plane base, stride and frame distance are 4-byte aligned: dword stores
+  int src_vec_ok;           // ... 16-byte aligned and sw % 16 == 0: every staged chunk is one dwordx4
+  int pad;
+};
+struct TiledArgs {
   const int16_t* wtab;      // OpenCV Q15 table (direct tiles)
   const uint32_t* wpack;    // kCubicPackDwords per phase (staged tiles)
   int nframes;
   int frames_per_block;
-  int src_vec_ok;           // plane base and stride are 16-byte aligned: dwordx4 chunk loads
-  int dst_dword_ok;         // plane base and stride are 4-byte aligned: dword stores
+  int nplanes;
+  int total_tiles;
+  int ring_bytes;           // LDS ring of the DMA-staged kernel
+  int pad;
+  TiledPlane plane[4];
 };
-hipError_t launch_remap_tiled_cubic(const TiledArgs& a, hipStream_t stream);
+// Fused launch over all planes; every plane must have src_vec_ok (chunks go global -> LDS by DMA).
+hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream);
+// One plane, chunks staged through registers (any alignment / width).
+hipError_t launch_remap_tiled_cubic_regs(const TiledArgs& a, hipStream_t stream);
 
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {

@@ -175,6 +175,11 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     return;
   }
   stream_ = own_stream_;
+  if (const char* e = getenv("T360_RING_KB")) {
+    const int v = atoi(e);
+    if (v >= 34 && v <= 160) ring_bytes_ = v * 1024;
+  }
+  if (getenv("T360_NO_DMA")) use_dma_ = false;
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4096) frames_per_block_ = v;
@@ -482,85 +487,126 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
   return check(launch_lowpass(a, n_frames, stream_), "low-pass launch");
 }
 
-// reference VideoFrameTransform::transformPlane (VideoFrameTransform.cpp:707-794), batched
-bool VideoFrameTransform::runPlane(const uint8_t* d_in, int64_t in_frame_bytes, int in_w, int in_h,
-                                   int in_stride, uint8_t* d_out, int64_t out_frame_bytes, int out_w,
-                                   int out_h, int out_stride, int n_frames, int idx, int imagePlaneIndex) {
-  PlaneState& p = planes_[idx];
+// reference VideoFrameTransform::transformPlane (VideoFrameTransform.cpp:707-794), for a set of
+// planes of a batch of frames: [low-pass each plane] -> gather.  Bicubic planes whose buffers are
+// 16-byte friendly are gathered by ONE fused launch of the DMA-ring kernel.
+bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frames) {
   const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
   const int interp = (int)ctx_.interpolation_alg;
   if (!valid_interp(interp)) {
     // reference :780-783: message, nothing written, still "true"
-    printf("Could not find interpolation algorithm for plane %d", imagePlaneIndex);
+    for (int k = 0; k < njobs; k++) printf("Could not find interpolation algorithm for plane %d", jobs[k].image_plane);
     return true;
   }
-  if (out_h != p.map_h || out_w != p.map_w) {
-    printf("Could not transform the plane %d. Error: supersampled output (width/height_scale_factor != 1, "
-           "cv::resize INTER_AREA) is not implemented on the HIP path yet\n", imagePlaneIndex);
-    return false;
+  for (int k = 0; k < njobs; k++) {
+    const PlaneState& p = planes_[jobs[k].idx];
+    if (jobs[k].out_h != p.map_h || jobs[k].out_w != p.map_w) {
+      printf("Could not transform the plane %d. Error: supersampled output (width/height_scale_factor != 1, "
+             "cv::resize INTER_AREA) is not implemented on the HIP path yet\n", jobs[k].image_plane);
+      return false;
+    }
   }
-  const uint8_t* src = d_in;
-  int64_t src_frame_bytes = in_frame_bytes;
-  int sstride = in_stride;
+
+  // ---- stage 1: segmented low-pass into the scratch planes (filterPlane, :621-704) ----
+  struct Src {
+    const uint8_t* ptr;
+    int64_t frame_bytes;
+    int stride;
+  };
+  std::vector<Src> srcs((size_t)njobs);
   if (ctx_.enable_low_pass_filter) {
-    const int bstride = (in_w + 255) & ~255;
-    const int64_t plane_bytes = (int64_t)bstride * in_h;
-    if (!blurred_.reserve((size_t)plane_bytes * (size_t)n_frames)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
-    if (!runLowpass(p, d_in, in_frame_bytes, in_stride, blurred_.as<uint8_t>(), plane_bytes, bstride, in_w,
-                    in_h, n_frames, imagePlaneIndex))
-      return false;
-    src = blurred_.as<uint8_t>();
-    src_frame_bytes = plane_bytes;
-    sstride = bstride;
+    size_t total = 0;
+    std::vector<size_t> offs((size_t)njobs);
+    for (int k = 0; k < njobs; k++) {
+      const int bstride = (jobs[k].in_w + 255) & ~255;
+      offs[(size_t)k] = total;
+      total += (size_t)bstride * jobs[k].in_h * (size_t)n_frames;
+    }
+    if (!blurred_.reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
+    for (int k = 0; k < njobs; k++) {
+      const PlaneJob& j = jobs[k];
+      const int bstride = (j.in_w + 255) & ~255;
+      const int64_t plane_bytes = (int64_t)bstride * j.in_h;
+      uint8_t* bl = blurred_.as<uint8_t>() + offs[(size_t)k];
+      if (!runLowpass(planes_[j.idx], j.in, j.in_frame_bytes, j.in_stride, bl, plane_bytes, bstride, j.in_w, j.in_h,
+                      n_frames, j.image_plane))
+        return false;
+      srcs[(size_t)k] = Src{bl, plane_bytes, bstride};
+    }
+  } else {
+    for (int k = 0; k < njobs; k++) srcs[(size_t)k] = Src{jobs[k].in, jobs[k].in_frame_bytes, jobs[k].in_stride};
   }
-  if (idx != 0 && barrel) {  // :743-747
-    if (!check(launch_fill_plane(d_out, out_frame_bytes, out_w, out_h, out_stride, 128, n_frames, stream_),
-               "fill launch"))
-      return false;
+
+  // ---- stage 2: gather ----
+  TiledArgs fused;
+  memset(&fused, 0, sizeof(fused));
+  fused.wtab = weights_.as<int16_t>();
+  fused.wpack = weights_pack_.as<uint32_t>();
+  fused.nframes = n_frames;
+  fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
+  fused.ring_bytes = ring_bytes_;
+  const bool multi = n_frames > 1;
+  for (int k = 0; k < njobs; k++) {
+    const PlaneJob& j = jobs[k];
+    PlaneState& p = planes_[j.idx];
+    const Src& s = srcs[(size_t)k];
+    if (j.idx != 0 && barrel) {  // :743-747
+      if (!check(launch_fill_plane(j.out, j.out_frame_bytes, j.out_w, j.out_h, j.out_stride, 128, n_frames, stream_),
+                 "fill launch"))
+        return false;
+    }
+    if (p.plan.valid && interp == CUBIC && !barrel && j.in_w == p.in_w && j.in_h == p.in_h) {
+      TiledPlane tp;
+      memset(&tp, 0, sizeof(tp));
+      tp.src = s.ptr;
+      tp.src_frame_bytes = s.frame_bytes;
+      tp.dst = j.out;
+      tp.dst_frame_bytes = j.out_frame_bytes;
+      tp.sw = j.in_w;
+      tp.sh = j.in_h;
+      tp.sstride = s.stride;
+      tp.dw = j.out_w;
+      tp.dh = j.out_h;
+      tp.dstride = j.out_stride;
+      tp.tiles = p.plan.tiles.as<TileDesc>();
+      tp.tlut = p.plan.tlut.as<uint32_t>();
+      tp.lut = p.lut.as<LutEntry>();
+      tp.ntiles = p.plan.ntiles;
+      tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
+                        (!multi || (j.out_frame_bytes & 3) == 0);
+      tp.src_vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
+                      (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
+      if (tp.src_vec_ok && use_dma_ && fused.nplanes < 4) {
+        fused.plane[fused.nplanes++] = tp;
+        fused.total_tiles += tp.ntiles;
+      } else {
+        TiledArgs one = fused;
+        one.nplanes = 1;
+        one.plane[0] = tp;
+        one.total_tiles = tp.ntiles;
+        if (!check(launch_remap_tiled_cubic_regs(one, stream_), "tiled remap launch")) return false;
+      }
+      continue;
+    }
+    GatherArgs a;
+    a.src = s.ptr;
+    a.src_frame_bytes = s.frame_bytes;
+    a.sw = j.in_w;
+    a.sh = j.in_h;
+    a.sstride = s.stride;
+    a.dst = j.out;
+    a.dst_frame_bytes = j.out_frame_bytes;
+    a.dw = j.out_w;
+    a.dh = j.out_h;
+    a.dstride = j.out_stride;
+    a.lut = p.lut.as<LutEntry>();
+    a.wtab = weights_.as<int16_t>();
+    a.interp = interp;
+    a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
+    if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
   }
-  if (p.plan.valid && interp == CUBIC && !barrel && in_w == p.in_w && in_h == p.in_h) {
-    TiledArgs ta;
-    ta.src = src;
-    ta.src_frame_bytes = src_frame_bytes;
-    ta.sw = in_w;
-    ta.sh = in_h;
-    ta.sstride = sstride;
-    ta.dst = d_out;
-    ta.dst_frame_bytes = out_frame_bytes;
-    ta.dw = out_w;
-    ta.dh = out_h;
-    ta.dstride = out_stride;
-    ta.tiles = p.plan.tiles.as<TileDesc>();
-    ta.ntiles = p.plan.ntiles;
-    ta.tlut = p.plan.tlut.as<uint32_t>();
-    ta.lut = p.lut.as<LutEntry>();
-    ta.wtab = weights_.as<int16_t>();
-    ta.wpack = weights_pack_.as<uint32_t>();
-    ta.nframes = n_frames;
-    ta.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
-    const bool multi = n_frames > 1;
-    ta.src_vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (sstride & 15) == 0 &&
-                    (!multi || (src_frame_bytes & 15) == 0);
-    ta.dst_dword_ok = (reinterpret_cast<uintptr_t>(d_out) & 3) == 0 && (out_stride & 3) == 0 &&
-                      (!multi || (out_frame_bytes & 3) == 0);
-    return check(launch_remap_tiled_cubic(ta, stream_), "tiled remap launch");
-  }
-  GatherArgs a;
-  a.src = src;
-  a.src_frame_bytes = src_frame_bytes;
-  a.sw = in_w;
-  a.sh = in_h;
-  a.sstride = sstride;
-  a.dst = d_out;
-  a.dst_frame_bytes = out_frame_bytes;
-  a.dw = out_w;
-  a.dh = out_h;
-  a.dstride = out_stride;
-  a.lut = p.lut.as<LutEntry>();
-  a.wtab = weights_.as<int16_t>();
-  a.interp = interp;
-  a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
-  return check(launch_remap_gather(a, n_frames, stream_), "remap launch");
+  if (fused.nplanes > 0 && !check(launch_remap_tiled_cubic_dma(fused, stream_), "tiled remap launch")) return false;
+  return true;
 }
 
 // reference VideoFrameTransform::transformFramePlane (VideoFrameTransform.cpp:1319-1351)
@@ -612,9 +658,9 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   }
   (void)in_bytes;
   (void)out_bytes;
-  if (!runPlane(d_in, 0, inputWidth, inputHeight, in_stride, d_out, 0, outputWidth, outputHeight, out_stride, 1,
-                idx, imagePlaneIndex))
-    return false;
+  const PlaneJob job{d_in, 0, inputWidth, inputHeight, in_stride, d_out, 0, outputWidth, outputHeight, out_stride, idx,
+                     imagePlaneIndex};
+  if (!runPlanes(&job, 1, 1)) return false;
   if (ok == PtrKind::Host) {
     if (!check(hipMemcpy2DAsync(outputData, (size_t)outputWidthWithPadding, d_out, (size_t)out_stride,
                                 (size_t)outputWidth, (size_t)outputHeight, hipMemcpyDeviceToHost, stream_),
@@ -635,6 +681,7 @@ bool VideoFrameTransform::transformFrames(const uint8_t* d_in, int64_t in_frame_
   }
   if (n_frames == 0) return true;
   DeviceGuard g(device_);
+  std::vector<PlaneJob> jobs;
   for (int k = 0; k < n_planes; k++) {
     const T360PlaneDesc& d = planes[k];
     if (d.map_index < 0 || d.map_index >= kMaxMaps || !planes_[d.map_index].valid) {
@@ -646,11 +693,11 @@ bool VideoFrameTransform::transformFrames(const uint8_t* d_in, int64_t in_frame_
       printf("Could not transform the plane %d. Error: invalid plane description\n", k);
       return false;
     }
-    if (!runPlane(d_in + d.in_offset, in_frame_bytes, d.in_width, d.in_height, d.in_stride, d_out + d.out_offset,
-                  out_frame_bytes, d.out_width, d.out_height, d.out_stride, n_frames, d.map_index, k))
-      return false;
+    jobs.push_back(PlaneJob{d_in + d.in_offset, in_frame_bytes, d.in_width, d.in_height, d.in_stride,
+                            d_out + d.out_offset, out_frame_bytes, d.out_width, d.out_height, d.out_stride,
+                            d.map_index, k});
   }
-  return true;
+  return runPlanes(jobs.data(), (int)jobs.size(), n_frames);
 }
 
 bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int width, int height, int in_stride,

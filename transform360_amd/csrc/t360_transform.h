@@ -80,10 +80,18 @@ class VideoFrameTransform {
   bool check(hipError_t e, const char* what) const;
   bool ensureWeights();
   bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
-  // all-device core: one plane of n frames
-  bool runPlane(const uint8_t* d_in, int64_t in_frame_bytes, int in_w, int in_h, int in_stride,
-                uint8_t* d_out, int64_t out_frame_bytes, int out_w, int out_h, int out_stride,
-                int n_frames, int idx, int imagePlaneIndex);
+  // all-device core: a set of planes of n frames
+  struct PlaneJob {
+    const uint8_t* in;
+    int64_t in_frame_bytes;
+    int in_w, in_h, in_stride;
+    uint8_t* out;
+    int64_t out_frame_bytes;
+    int out_w, out_h, out_stride;
+    int idx;          // transformMatPlaneIndex
+    int image_plane;  // imagePlaneIndex (messages only, as in the reference)
+  };
+  bool runPlanes(const PlaneJob* jobs, int njobs, int n_frames);
   bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
                   int imagePlaneIndex);
@@ -97,7 +105,9 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  int frames_per_block_ = 8;  // frames one workgroup of the tiled gather walks with one tile
+  int ring_bytes_ = 40 * 1024;  // LDS ring of the DMA-staged gather (4 workgroups per CU)
+  bool use_dma_ = true;
+  int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
 };
