@@ -60,11 +60,16 @@ struct TiledArgs {
   int nplanes;
   int total_tiles;
   int ring_bytes;           // LDS ring of the DMA-staged kernel
-  int pad;
+  int loader_waves;         // DMA loader waves per workgroup (1..4) next to the 4 consumer waves
+  int debug;                // experiments (T360_DEBUG): bit2 no steady-state DMA, bit3 no gather
+  unsigned long long* trace;  // optional: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   TiledPlane plane[4];
 };
 // Fused launch over all planes; every plane must have src_vec_ok (chunks go global -> LDS by DMA).
 hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream);
+// Direct (unstaged) tiles of one plane: `tiles` holds ntiles kTileDirect16 descriptors.
+hipError_t launch_remap_direct_cubic(const TiledPlane& pl, const TileDesc* tiles, int ntiles, const int16_t* wtab,
+                                     int nframes, hipStream_t stream);
 // One plane, chunks staged through registers (any alignment / width).
 hipError_t launch_remap_tiled_cubic_regs(const TiledArgs& a, hipStream_t stream);
 

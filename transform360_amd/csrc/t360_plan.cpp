@@ -25,7 +25,7 @@ struct Box {
 };
 
 // b: {minx, maxx, minx_shifted, maxx_shifted, miny, maxy} of pixel-centre taps
-Box make_box(const int* b, int halo_lo, int halo_hi) {
+Box make_box(const int* b, int halo_lo, int halo_hi, int max_chunks) {
   Box r{};
   r.empty = b[0] > b[1];
   if (r.empty) return r;
@@ -38,18 +38,20 @@ Box make_box(const int* b, int halo_lo, int halo_hi) {
   r.y0 = b[4] - halo_lo;
   r.rows = (b[5] + halo_hi) - r.y0 + 1;
   r.fits = r.cpr * kStageChunk <= kStageMaxCols && r.rows <= kStageMaxRows &&
-           r.cpr * r.rows <= 256 * kStageChunksPerLane;
+           r.cpr * r.rows <= max_chunks;
   return r;
 }
 
 }  // namespace
 
-bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, hipStream_t stream,
-                       GatherPlan* plan) {
+bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, int max_box_bytes,
+                       hipStream_t stream, GatherPlan* plan) {
   plan->valid = false;
   plan->ntiles = 0;
   if (ksize != 4) return true;  // only the bicubic kernel is tiled in this round
   const int halo_lo = ksize / 2 - 1, halo_hi = ksize / 2;
+  int max_chunks = max_box_bytes / kStageChunk;
+  if (max_chunks > 256 * kStageChunksPerLane) max_chunks = 256 * kStageChunksPerLane;
   const int tiles_x = (dw + 31) / 32, tiles_y = (dh + 31) / 32;
   const size_t nmacro = (size_t)tiles_x * tiles_y;
 
@@ -61,14 +63,14 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
     return false;
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
 
-  std::vector<TileDesc> tiles;
+  std::vector<TileDesc> tiles, direct;
   tiles.reserve(nmacro);
   int64_t tlut_words = 0, staged_bytes = 0;
   int n32 = 0, n16 = 0, ndirect = 0;
   for (int ty = 0; ty < tiles_y; ty++)
     for (int tx = 0; tx < tiles_x; tx++) {
       const int* b = &boxes[((size_t)ty * tiles_x + tx) * 30];
-      const Box big = make_box(b, halo_lo, halo_hi);
+      const Box big = make_box(b, halo_lo, halo_hi, max_chunks);
       if (big.empty) continue;
       const int ox = tx * 32, oy = ty * 32;
       auto emit = [&](const Box& bx, int kind, int tox, int toy, int edge) {
@@ -86,31 +88,34 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
         if (kind == kTileStaged32) tlut_words += 1024, n32++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
         else if (kind == kTileStaged16) tlut_words += 256, n16++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
         else ndirect++;
-        tiles.push_back(t);
+        (kind == kTileDirect16 ? direct : tiles).push_back(t);
       };
       if (big.fits) {
         emit(big, kTileStaged32, ox, oy, 32);
         continue;
       }
       for (int qd = 0; qd < 4; qd++) {
-        const Box sub = make_box(b + 6 * (1 + qd), halo_lo, halo_hi);
+        const Box sub = make_box(b + 6 * (1 + qd), halo_lo, halo_hi, max_chunks);
         if (sub.empty) continue;
         emit(sub, sub.fits ? kTileStaged16 : kTileDirect16, ox + (qd & 1) * 16, oy + (qd >> 1) * 16, 16);
       }
     }
   if (tiles.size() > 0x7fffffff || tlut_words > 0x7fffffff) return false;
 
+  // staged tiles first, direct tiles behind them in the same buffer
+  const size_t nstaged = tiles.size();
+  tiles.insert(tiles.end(), direct.begin(), direct.end());
   if (!plan->tiles.reserve(tiles.size() * sizeof(TileDesc)) ||
       !plan->tlut.reserve((size_t)(tlut_words > 0 ? tlut_words : 1) * sizeof(uint32_t)))
     return false;
   if (hipMemcpyAsync(plan->tiles.as<void>(), tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
                      stream) != hipSuccess)
     return false;
-  if (launch_tile_lut(d_lut, dw, dh, sw, plan->tiles.as<TileDesc>(), (int)tiles.size(), halo_lo,
+  if (launch_tile_lut(d_lut, dw, dh, sw, plan->tiles.as<TileDesc>(), (int)nstaged, halo_lo,
                       plan->tlut.as<uint32_t>(), stream) != hipSuccess)
     return false;
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
-  plan->ntiles = (int)tiles.size();
+  plan->ntiles = (int)nstaged;
   plan->n32 = n32;
   plan->n16 = n16;
   plan->ndirect = ndirect;

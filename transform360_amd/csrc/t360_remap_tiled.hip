@@ -66,10 +66,14 @@ __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t
     const int rx = e & 1023, ry = (e >> 10) & 255, frac = (e >> 18) & 1023;
     s.off[p] = s.live[p] ? ry * pitch + rx : 0;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(wpack + (size_t)frac * kCubicPackDwords);
-    const uint4 h = wp[0], l = wp[1], c = wp[2];
+    const uint4 h = wp[0], l = wp[1];
     s.wh[p][0] = h.x; s.wh[p][1] = h.y; s.wh[p][2] = h.z; s.wh[p][3] = h.w;
     s.wl[p][0] = l.x; s.wl[p][1] = l.y; s.wl[p][2] = l.z; s.wl[p][3] = l.w;
-    s.bias[p] = (int)c.x;
+    // rounding + bias term 16384 + 128*256*SUM(wh): SUM of the 16 signed high bytes by dot4 with ones
+    int sh = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) sh = __builtin_amdgcn_sdot4((int)s.wh[p][r], 0x01010101, sh, false);
+    s.bias[p] = (1 << (kCoefBits - 1)) + 128 * 256 * sh;
   }
 }
 
@@ -89,18 +93,35 @@ __device__ __forceinline__ void pin_pixels(PixelSetup<NPX>& s) {
 // one frame of one tile: gather from the staged box at `box`, write the output pixels
 template <int NPX>
 __device__ __forceinline__ void gather_store(const PixelSetup<NPX>& s, const uint8_t* __restrict__ box, int pitch,
-                                             uint8_t* __restrict__ d, bool dword_store) {
-  int v[NPX];
+                                             uint8_t* __restrict__ d, int dstride, bool dword_store) {
+  // Phase 1: every LDS read of the frame in flight at once (16 ds_read2_b32 for 4 pixels) --
+  // one LDS round trip per frame instead of one per pixel; phase 2: the dot products.
+  uint32_t lo32[NPX][4], hi32[NPX][4];
 #pragma unroll
   for (int p = 0; p < NPX; p++) {
     const int a4 = s.off[p] & ~3;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
+      lo32[p][r] = q[0];
+      hi32[p][r] = q[1];
+    }
+  }
+  // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
+#pragma unroll
+  for (int p = 0; p < NPX; p++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(lo32[p][r]), "+v"(hi32[p][r]));
+  }
+  int v[NPX];
+#pragma unroll
+  for (int p = 0; p < NPX; p++) {
     const uint32_t sh = (uint32_t)(s.off[p] & 3) * 8u;
     int hi = 0;
     uint32_t lo = (uint32_t)s.bias[p];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
-      const uint32_t px4 = __builtin_amdgcn_alignbit(q[1], q[0], sh);  // 4 consecutive source bytes
+      const uint32_t px4 = __builtin_amdgcn_alignbit(hi32[p][r], lo32[p][r], sh);  // 4 consecutive source bytes
       hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[p][r], hi, false);
       lo = __builtin_amdgcn_udot4(px4, s.wl[p][r], lo, false);
     }
@@ -108,47 +129,52 @@ __device__ __forceinline__ void gather_store(const PixelSetup<NPX>& s, const uin
     v[p] = sat_u8(sum >> kCoefBits);
   }
   if (NPX == 4) {
+    // v[k] is the pixel of column x = lane & 31 in row 4*(lane >> 5) + k of the tile.
     if (dword_store) {
-      *reinterpret_cast<uint32_t*>(d) =
-          (uint32_t)v[0] | ((uint32_t)v[1 % NPX] << 8) | ((uint32_t)v[2 % NPX] << 16) | ((uint32_t)v[3 % NPX] << 24);
+      // 4x4 byte transpose inside each quad of lanes (DPP quad broadcasts + v_perm), so that
+      // lane i of a quad owns row i, columns 4j..4j+3 -> one coalesced dword store per lane
+      const uint32_t b = (uint32_t)v[0] | ((uint32_t)v[1 % NPX] << 8) | ((uint32_t)v[2 % NPX] << 16) |
+                         ((uint32_t)v[3 % NPX] << 24);
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x00, 0xf, 0xf, false);  // quad_perm 0,0,0,0
+      const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x55, 0xf, 0xf, false);  // 1,1,1,1
+      const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xaa, 0xf, 0xf, false);  // 2,2,2,2
+      const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xff, 0xf, 0xf, false);  // 3,3,3,3
+      const uint32_t i = threadIdx.x & 3;
+      const uint32_t sel_lo = 0x0c0c0000u | ((4u + i) << 8) | i;           // [b0.byte_i, b1.byte_i, 0, 0]
+      const uint32_t sel_hi = 0x00000c0cu | ((4u + i) << 24) | (i << 16);  // [0, 0, b2.byte_i, b3.byte_i]
+      const uint32_t w = __builtin_amdgcn_perm(b1, b0, sel_lo) | __builtin_amdgcn_perm(b3, b2, sel_hi);
+      *reinterpret_cast<uint32_t*>(d) = w;
     } else {
 #pragma unroll
       for (int p = 0; p < NPX; p++)
-        if (s.live[p]) d[p] = (uint8_t)v[p];
+        if (s.live[p]) d[(size_t)p * dstride] = (uint8_t)v[p];
     }
   } else {
     if (s.live[0]) d[0] = (uint8_t)v[0];
   }
 }
 
+// Where a lane's output goes.  32x32 tiles: with dword stores lane (x, band) writes row
+// 4*band + (x & 3), columns (x & ~3)..+3 after the quad transpose; with byte stores it writes its
+// own column x, rows 4*band + 0..3.
 template <int NPX>
-__device__ __forceinline__ size_t out_pos(const TiledPlane& pl, const TileDesc& t) {
+__device__ __forceinline__ size_t out_pos(const TiledPlane& pl, const TileDesc& t, bool dword_store) {
   const int tid = threadIdx.x;
   int ox, oy;
   if (NPX == 4) {
-    ox = t.ox + (tid & 7) * 4;
-    oy = t.oy + (tid >> 3);
+    const int x = tid & 31, band = tid >> 5;
+    if (dword_store) {
+      ox = t.ox + (x & ~3);
+      oy = t.oy + band * 4 + (x & 3);
+    } else {
+      ox = t.ox + x;
+      oy = t.oy + band * 4;
+    }
   } else {
     ox = t.ox + (tid & 15);
     oy = t.oy + (tid >> 4);
   }
   return (size_t)oy * pl.dstride + ox;
-}
-
-// tiles whose source box does not fit the staging budget (the four tiles around each pole).
-// Arguments by value: taking the address of the plane descriptor would force it into scratch.
-__device__ __noinline__ void direct_tile(const uint8_t* __restrict__ src, int64_t src_frame_bytes, int sw, int sh,
-                                         int sstride, uint8_t* __restrict__ dst, int64_t dst_frame_bytes, int dw,
-                                         int dh, int dstride, const LutEntry* __restrict__ lut,
-                                         const int16_t* __restrict__ wtab, int tox, int toy, int f0, int f1) {
-  const int tid = threadIdx.x;
-  const int ox = tox + (tid & 15), oy = toy + (tid >> 4);
-  if (ox >= dw || oy >= dh) return;
-  const LutEntry e = lut[(size_t)oy * dw + ox];
-  for (int f = f0; f < f1; f++) {
-    const int v = sample<4, false>(src + (size_t)f * src_frame_bytes, sw, sh, sstride, wtab, e);
-    dst[(size_t)f * dst_frame_bytes + (size_t)oy * dstride + ox] = (uint8_t)v;
-  }
 }
 
 // XCD-aware order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch");
@@ -161,107 +187,189 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 }
 
 // ============================ variant 1: DMA ring (main path) ================================
+// Workgroup = 5 waves: wave 4 is the LOADER, waves 0-3 are CONSUMERS (persistent loader/consumer
+// split, cdna_hip_programming.md 5.6).  The loader's instruction stream is only address setup,
+// global_load_lds_dwordx4 and counted vmcnt waits; the consumers' frame loop is only
+// barrier -> ds_read2 -> dot4 -> store.  They meet at ONE s_barrier per frame:
+//     loader  : wait until frame i has landed | BARRIER i | refill the slot frame i-1 used
+//     consumer:                                 BARRIER i | gather frame i from its slot, store
+// The loader's vmcnt stream holds nothing but its own in-order DMA loads, so the count is exact.
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+constexpr int kLoaderWave = 4;
+
+// optional per-workgroup phase timestamps (debug builds of the schedule, T360_TRACE)
+__device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
+  if (a.trace && (threadIdx.x & 63) == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.trace[wg * 8 + slot] = wall_clock64();
+  }
+}
+constexpr int kMaxLoaderInstr = kStageChunksPerLane * 4;  // 16 x (64 lanes x 16 B) = 16 KiB box
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate, max 63)
 __device__ __forceinline__ void wait_vmcnt(int n) {
   switch (n) {
 #define T360_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     T360_W(0) T360_W(1) T360_W(2) T360_W(3) T360_W(4) T360_W(5) T360_W(6) T360_W(7)
     T360_W(8) T360_W(9) T360_W(10) T360_W(11) T360_W(12) T360_W(13) T360_W(14) T360_W(15)
     T360_W(16) T360_W(17) T360_W(18) T360_W(19) T360_W(20) T360_W(21) T360_W(22) T360_W(23)
-    T360_W(24) T360_W(25) T360_W(26) T360_W(27) T360_W(28)
+    T360_W(24) T360_W(25) T360_W(26) T360_W(27) T360_W(28) T360_W(29) T360_W(30) T360_W(31)
+    T360_W(32) T360_W(33) T360_W(34) T360_W(35) T360_W(36) T360_W(37) T360_W(38) T360_W(39)
+    T360_W(40) T360_W(41) T360_W(42) T360_W(43) T360_W(44) T360_W(45) T360_W(46) T360_W(47)
+    T360_W(48) T360_W(49) T360_W(50) T360_W(51) T360_W(52) T360_W(53) T360_W(54) T360_W(55)
+    T360_W(56) T360_W(57) T360_W(58) T360_W(59) T360_W(60) T360_W(61) T360_W(62) T360_W(63)
 #undef T360_W
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-// 64 lanes x 16 bytes global -> LDS; lane i lands at lds_dst + 16*i.  hipcc does not count this
-// load (cdna_hip_programming.md 5.7): completion is ours to track with wait_vmcnt().
-__device__ __forceinline__ void dma16(const uint8_t* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+// One frame of one tile, global -> LDS by DMA: NJ x (64 lanes x 16 bytes).  Lane i of
+// instruction j lands at lds_dst + 1024*j + 16*i.  SGPR-base + 32-bit VGPR-offset addressing, so
+// per frame only the scalar base changes; M0 (the LDS destination) is written and stepped inside
+// the statement that uses it.  hipcc does not count these loads (cdna_hip_programming.md 5.7):
+// completion is ours to track with wait_vmcnt().
+template <int NJ>
+__device__ __forceinline__ void dma_frame(const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
+                                          const int (&off)[16]) {
+  static_assert(NJ >= 1 && NJ <= 16, "1..16 DMA instructions per frame");
+#define T360_DMA(j)                                                                                   \
+  if (NJ > j)                                                                                         \
+    asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2\n\ts_nop 0" ::"v"(off[j]), \
+                 "s"(frame_base), "s"(lds_step)                                                       \
+                 : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
+  T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3) T360_DMA(4) T360_DMA(5) T360_DMA(6) T360_DMA(7)
+  T360_DMA(8) T360_DMA(9) T360_DMA(10) T360_DMA(11) T360_DMA(12) T360_DMA(13) T360_DMA(14) T360_DMA(15)
+#undef T360_DMA
 }
 
-template <int NPX>
-__device__ __forceinline__ void staged_tile_dma(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
-                                                uint8_t* __restrict__ lds, int f0, int f1) {
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pitch = (int)t.cpr * kStageChunk;
-  const int nch = (int)t.cpr * (int)t.rows;
-  const int slot_bytes = (nch * kStageChunk + 16 + 63) & ~63;  // +16: hi dword of the last row window
-  int K = a.ring_bytes / slot_bytes;
-  K = K > kRingMaxSlots ? kRingMaxSlots : K;  // the plan guarantees K >= 2
+// run-time NJ -> the unrolled statement above (wave-uniform switch, loader wave only)
+__device__ __forceinline__ void dma_frame_n(int nj, const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
+                                            const int (&off)[16]) {
+  switch (nj) {
+#define T360_C(n) case n: dma_frame<n>(frame_base, lds_dst, lds_step, off); break;
+    T360_C(1) T360_C(2) T360_C(3) T360_C(4) T360_C(5) T360_C(6) T360_C(7) T360_C(8)
+    T360_C(9) T360_C(10) T360_C(11) T360_C(12) T360_C(13) T360_C(14) T360_C(15) T360_C(16)
+#undef T360_C
+    default: break;
+  }
+}
 
-  PixelSetup<NPX> px;
-  load_pixels<NPX>(pl, a.wpack, t, pitch, px);
+__device__ __forceinline__ void frame_barrier() {
+  // a bare s_barrier: __syncthreads() would add fences whose waits could drain the DMA ring
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-  // staging assignments: lane owns chunks tid, tid+256, ... ; chunk q lives at LDS byte 16*q
-  int goff[kStageChunksPerLane];
-  int my_nld = 0;  // DMA instructions THIS WAVE issues per frame (wave-uniform)
+// ring geometry of one tile (identical in loader and consumers)
+struct RingGeom {
+  int pitch, nch, slot_bytes, K;
+};
+__device__ __forceinline__ RingGeom ring_geom(const TileDesc& t, int ring_bytes) {
+  RingGeom g;
+  g.pitch = (int)t.cpr * kStageChunk;
+  g.nch = (int)t.cpr * (int)t.rows;
+  const int nj = (g.nch + 63) >> 6;                      // DMA instructions per frame (1 KiB each)
+  g.slot_bytes = nj * 1024 + 64;                         // whole pieces (+ the hi dword of the last window)
+  int K = ring_bytes / g.slot_bytes;                     // the plan guarantees >= 2
+  K = K > kRingMaxSlots ? kRingMaxSlots : K;
+  while (K > 2 && (K - 2) * nj > 63) K--;                // vmcnt is a 6-bit counter
+  g.K = K;
+  return g;
+}
+
+// `which` of `nloaders` loader waves: it owns the 1 KiB pieces j = which, which + nloaders, ...
+__device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
+                                            uint32_t lds_base, int f0, int f1, int which, int nloaders) {
+  const int lane = threadIdx.x & 63;
+  const RingGeom g = ring_geom(t, a.ring_bytes);
+  const int nj_all = (g.nch + 63) >> 6;
+  const int nj = (nj_all - which + nloaders - 1) / nloaders;  // pieces of this loader (may be 0)
+  // chunk q = lane + 64*j lives at LDS byte 16*q of the slot; its source offset inside the plane
+  // is fixed per tile.  Lanes past the end of the box re-read chunk 0 into the slot's padding:
+  // every DMA instruction runs with all 64 lanes (no exec juggling in the issue path).
+  const uint32_t inv = (65536u + (uint32_t)t.cpr - 1u) / (uint32_t)t.cpr;  // exact q / cpr for q < 1024
+  int goff[kMaxLoaderInstr];
 #pragma unroll
-  for (int c = 0; c < kStageChunksPerLane; c++) {
-    const int q = tid + c * 256;
-    goff[c] = -1;
-    if (q < nch) {
-      const int r = q / (int)t.cpr, cc = q - r * (int)t.cpr;
+  for (int j = 0; j < kMaxLoaderInstr; j++) {
+    goff[j] = 0;
+    if (j < nj) {  // wave-uniform
+      int q = lane + 64 * (which + j * nloaders);
+      q = q < g.nch ? q : 0;
+      const int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
       const int sy = wrap_coord(t.y0 + r, pl.sh);
-      int sx = t.x0 + cc * kStageChunk;  // multiple of 16; plane width is a multiple of 16 here
+      int sx = t.x0 + cc * kStageChunk;  // multiple of 16; the plane width is a multiple of 16 here
       if (sx < 0)
         sx += pl.sw;
       else if (sx >= pl.sw)
         sx -= pl.sw;
-      goff[c] = sy * pl.sstride + sx;
+      goff[j] = sy * pl.sstride + sx;
     }
-    if (c * 256 + wave * 64 < nch) my_nld++;
   }
-  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;  // LDS byte address of the ring
-
   auto issue = [&](int f, int slot) {
-    const uint8_t* __restrict__ base = pl.src + (size_t)f * pl.src_frame_bytes;
-    const uint32_t sbase = lds_base + (uint32_t)(slot * slot_bytes + wave * 64 * kStageChunk);
-#pragma unroll
-    for (int c = 0; c < kStageChunksPerLane; c++) {
-      if (c * 256 + wave * 64 < nch) {  // wave-uniform: the instruction count per wave is exact
-        if (goff[c] >= 0)
-          dma16(base + goff[c], (uint32_t)__builtin_amdgcn_readfirstlane((int)(sbase + (uint32_t)(c * 256 * kStageChunk))));
-      }
-    }
+    dma_frame_n(nj, pl.src + (size_t)f * pl.src_frame_bytes,
+                lds_base + (uint32_t)(slot * g.slot_bytes + which * 1024), (uint32_t)(nloaders * 1024), goff);
   };
-
-  const size_t dpos = out_pos<NPX>(pl, t);
-  const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
-
-  // hipcc's own loads (LUT words, weights) must not sit in the queue behind the DMA
-  pin_pixels<NPX>(px);
-
   const int nf = f1 - f0;
+  const int K = g.K;
+  if (which == 0) trace_mark(a, 1);
   for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
-  int slot = 0, fill = (K - 1) % K;
+  if (which == 0) trace_mark(a, 2);
+  int fill = (K - 1) % K;
+  unsigned long long acc_wait = 0, acc_bar = 0, acc_issue = 0;
+  const bool tracing = a.trace != nullptr && (a.debug & 16);
   for (int i = 0; i < nf; i++) {
-    // DMA loads of this wave younger than frame i's: frames i+1 .. min(i+K-2, nf-1)
-    const int younger = min(K - 2, nf - 1 - i);
-    wait_vmcnt(younger * my_nld);
-    // frame i's box is complete for every wave; everyone left frame i-1's slot.  A bare
-    // s_barrier: __syncthreads() would add fences whose waits could drain the DMA ring.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (i + K - 1 < nf) issue(f0 + i + K - 1, fill);
-    gather_store<NPX>(px, lds + slot * slot_bytes, pitch,
-                      pl.dst + (size_t)(f0 + i) * pl.dst_frame_bytes + dpos, dword_store);
-    slot = slot + 1 == K ? 0 : slot + 1;
+    // loads younger than frame i's: frames i+1 .. min(i+K-2, nf-1), nj instructions each
+    unsigned long long c0 = tracing ? wall_clock64() : 0;
+    wait_vmcnt((a.debug & 4) ? 0 : min(K - 2, nf - 1 - i) * nj);
+    unsigned long long c1 = tracing ? wall_clock64() : 0;
+    if (i == 0 && which == 0 && !tracing) trace_mark(a, 3);
+    frame_barrier();  // frame i is visible to the consumers; they have left frame i-1's slot
+    unsigned long long c2 = tracing ? wall_clock64() : 0;
+    if (i + K - 1 < nf && !(a.debug & 4)) issue(f0 + i + K - 1, fill);
     fill = fill + 1 == K ? 0 : fill + 1;
+    if (tracing) {
+      acc_wait += c1 - c0;
+      acc_bar += c2 - c1;
+      acc_issue += wall_clock64() - c2;
+    }
   }
+  if (tracing && which == 0 && (threadIdx.x & 63) == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.trace[wg * 8 + 1] = acc_wait;   // loader: total time in counted vmcnt waits
+    a.trace[wg * 8 + 2] = acc_bar;    // loader: total time at the frame barrier (waiting for consumers)
+    a.trace[wg * 8 + 3] = acc_issue;  // loader: total time issuing DMA
+    a.trace[wg * 8 + 4] = (unsigned long long)(nj * 1000 + K);
+  }
+  if (which == 0) trace_mark(a, 6);
 }
 
-__global__ __launch_bounds__(256) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
+template <int NPX>
+__device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
+                                               const uint8_t* __restrict__ lds, int f0, int f1) {
+  const RingGeom g = ring_geom(t, a.ring_bytes);
+  PixelSetup<NPX> px;
+  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px);
+  if (a.trace && !(a.debug & 16)) {
+    pin_pixels<NPX>(px);  // make the compiler wait for the loads before the timestamp
+    if (threadIdx.x < 64) trace_mark(a, 4);
+  }
+  const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
+  uint8_t* __restrict__ d = pl.dst + (size_t)f0 * pl.dst_frame_bytes + out_pos<NPX>(pl, t, dword_store);
+  const uint8_t* __restrict__ box = lds;
+  const uint8_t* const ring_end = lds + g.K * g.slot_bytes;
+  const int nf = f1 - f0;
+  for (int i = 0; i < nf; i++) {
+    frame_barrier();
+    if (!(a.debug & 8)) gather_store<NPX>(px, box, g.pitch, d, pl.dstride, dword_store);
+    d += pl.dst_frame_bytes;
+    box += g.slot_bytes;
+    if (box == ring_end) box = lds;
+    if (i == 0 && threadIdx.x < 64) trace_mark(a, 5);
+  }
+  if (threadIdx.x < 64) trace_mark(a, 7);
+}
+
+__global__ __launch_bounds__(512, 1) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
   int b = xcd_contiguous(blockIdx.x, a.total_tiles);
   // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
@@ -282,13 +390,15 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_dma_kernel(TiledArgs a)
   const TileDesc t = pl.tiles[b];
   const int f0 = blockIdx.y * a.frames_per_block;
   const int f1 = min(f0 + a.frames_per_block, a.nframes);
-  if (t.kind == kTileStaged32)
-    staged_tile_dma<4>(a, pl, t, lds, f0, f1);
-  else if (t.kind == kTileStaged16)
-    staged_tile_dma<1>(a, pl, t, lds, f0, f1);
-  else
-    direct_tile(pl.src, pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, pl.dst, pl.dst_frame_bytes, pl.dw, pl.dh,
-                pl.dstride, pl.lut, a.wtab, t.ox, t.oy, f0, f1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave == 0) trace_mark(a, 0);
+  if (wave >= kLoaderWave) {
+    loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
+  } else if (t.kind == kTileStaged32) {
+    consumer_waves<4>(a, pl, t, lds, f0, f1);
+  } else {
+    consumer_waves<1>(a, pl, t, lds, f0, f1);
+  }
 }
 
 // ===================== variant 2: chunks staged through registers ============================
@@ -359,14 +469,14 @@ __device__ __forceinline__ void staged_tile_regs(const TiledArgs& a, const Tiled
       if (loff[c] >= 0) *reinterpret_cast<uint4*>(lds + loff[c]) = stage[c];
   };
 
-  const size_t dpos = out_pos<NPX>(pl, t);
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
+  const size_t dpos = out_pos<NPX>(pl, t, dword_store);
   fetch(f0);
   commit();
   __syncthreads();
   for (int f = f0; f < f1; f++) {
     if (f + 1 < f1) fetch(f + 1);  // in flight while this frame is computed
-    gather_store<NPX>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, dword_store);
+    gather_store<NPX>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, pl.dstride, dword_store);
     __syncthreads();  // everyone is done reading this frame's box
     if (f + 1 < f1) {
       commit();
@@ -383,18 +493,39 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_regs_kernel(TiledArgs a
   const int f1 = min(f0 + a.frames_per_block, a.nframes);
   if (t.kind == kTileStaged32)
     staged_tile_regs<4>(a, pl, t, lds, f0, f1);
-  else if (t.kind == kTileStaged16)
-    staged_tile_regs<1>(a, pl, t, lds, f0, f1);
   else
-    direct_tile(pl.src, pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, pl.dst, pl.dst_frame_bytes, pl.dw, pl.dh,
-                pl.dstride, pl.lut, a.wtab, t.ox, t.oy, f0, f1);
+    staged_tile_regs<1>(a, pl, t, lds, f0, f1);
+}
+
+// ===================== tiles too large to stage: direct gather ================================
+// The few 16x16 tiles around each pole whose source box exceeds the staging budget (they span a
+// full quadrant of longitudes): one workgroup per (tile, frame), one pixel per
+// lane, 16 independent byte loads in flight per lane.
+__global__ __launch_bounds__(256) void remap_direct_cubic_kernel(TiledPlane pl, const TileDesc* __restrict__ tiles,
+                                                                 const int16_t* __restrict__ wtab) {
+  const TileDesc t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int ox = t.ox + (tid & 15), oy = t.oy + (tid >> 4);
+  if (ox >= pl.dw || oy >= pl.dh) return;
+  const int f = blockIdx.y;
+  const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
+  const int v = sample<4, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, wtab, e);
+  pl.dst[(size_t)f * pl.dst_frame_bytes + (size_t)oy * pl.dstride + ox] = (uint8_t)v;
 }
 
 }  // namespace
 
+hipError_t launch_remap_direct_cubic(const TiledPlane& pl, const TileDesc* tiles, int ntiles, const int16_t* wtab,
+                                     int nframes, hipStream_t stream) {
+  if (ntiles <= 0 || nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(remap_direct_cubic_kernel, dim3(ntiles, nframes, 1), dim3(256), 0, stream, pl, tiles, wtab);
+  return hipGetLastError();
+}
+
 hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) {
   if (a.total_tiles <= 0 || a.nframes <= 0) return hipSuccess;
   const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
+  const int nload = a.loader_waves < 1 ? 1 : (a.loader_waves > 4 ? 4 : a.loader_waves);
   static int configured_lds = 0;
   if (a.ring_bytes > 64 * 1024 && configured_lds < a.ring_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_dma_kernel),
@@ -402,7 +533,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
     if (e != hipSuccess) return e;
     configured_lds = a.ring_bytes;
   }
-  hipLaunchKernelGGL(remap_tiled_cubic_dma_kernel, dim3(a.total_tiles, groups, 1), dim3(256), (size_t)a.ring_bytes,
+  hipLaunchKernelGGL(remap_tiled_cubic_dma_kernel, dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload), (size_t)a.ring_bytes,
                      stream, a);
   return hipGetLastError();
 }

@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void tile_lut_kernel(const LutEntry* __restric
   for (int p = 0; p < npx; p++) {
     int ox, oy;
     if (t.kind == kTileStaged32) {
-      ox = t.ox + (tid & 7) * 4 + p;
-      oy = t.oy + (tid >> 3);
+      // lane = column (tid & 31) of a band of 4 rows: the 32 lanes of a half-wave read ONE
+      // source-row neighbourhood per instruction (conflict-free ds_read2_b32, see the gather)
+      ox = t.ox + (tid & 31);
+      oy = t.oy + (tid >> 5) * 4 + p;
     } else {
       ox = t.ox + (tid & 15);
       oy = t.oy + (tid >> 4);

@@ -177,9 +177,13 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   stream_ = own_stream_;
   if (const char* e = getenv("T360_RING_KB")) {
     const int v = atoi(e);
-    if (v >= 34 && v <= 160) ring_bytes_ = v * 1024;
+    if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
   }
   if (getenv("T360_NO_DMA")) use_dma_ = false;
+  if (const char* e = getenv("T360_LOADERS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4) loader_waves_ = v;
+  }
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4096) frames_per_block_ = v;
@@ -338,7 +342,9 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     const bool barrel = olay == LAYOUT_BARREL || olay == LAYOUT_BARREL_SPLIT;
     p.plan.valid = false;
     if (P.interp == CUBIC && !barrel && !getenv("T360_NO_TILED")) {
-      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, 4, stream_, &p.plan))
+      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, 4,
+                             ((ring_bytes_ / 2 - 64) / 1024) * 1024,  // a ring slot = whole KiB pieces + 64
+                             stream_, &p.plan))
         return check(hipErrorUnknown, "gather plan");
     }
   }
@@ -545,6 +551,8 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   fused.nframes = n_frames;
   fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
   fused.ring_bytes = ring_bytes_;
+  fused.loader_waves = loader_waves_;
+  fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
   const bool multi = n_frames > 1;
   for (int k = 0; k < njobs; k++) {
     const PlaneJob& j = jobs[k];
@@ -576,6 +584,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
                         (!multi || (j.out_frame_bytes & 3) == 0);
       tp.src_vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
                       (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
+      if (p.plan.ndirect > 0 &&
+          !check(launch_remap_direct_cubic(tp, tp.tiles + tp.ntiles, p.plan.ndirect, weights_.as<int16_t>(), n_frames,
+                                           stream_), "direct tiles launch"))
+        return false;
       if (tp.src_vec_ok && use_dma_ && fused.nplanes < 4) {
         fused.plane[fused.nplanes++] = tp;
         fused.total_tiles += tp.ntiles;
@@ -605,7 +617,29 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
     if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
   }
-  if (fused.nplanes > 0 && !check(launch_remap_tiled_cubic_dma(fused, stream_), "tiled remap launch")) return false;
+  if (fused.nplanes > 0) {
+    const char* trace_path = getenv("T360_TRACE");  // schedule debugging: dump per-workgroup timestamps
+    t360::DeviceBuffer trace;
+    size_t nwg = 0;
+    if (trace_path) {
+      const int groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+      nwg = (size_t)fused.total_tiles * groups;
+      if (trace.reserve(nwg * 8 * sizeof(unsigned long long)) &&
+          hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
+        fused.trace = trace.as<unsigned long long>();
+    }
+    if (!check(launch_remap_tiled_cubic_dma(fused, stream_), "tiled remap launch")) return false;
+    if (fused.trace) {
+      std::vector<unsigned long long> host(nwg * 8);
+      if (hipStreamSynchronize(stream_) == hipSuccess &&
+          hipMemcpy(host.data(), trace.as<void>(), nwg * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(trace_path, "wb")) {
+          fwrite(host.data(), 8, host.size(), f);
+          fclose(f);
+        }
+      }
+    }
+  }
   return true;
 }
 

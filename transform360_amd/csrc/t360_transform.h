@@ -105,8 +105,9 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  int ring_bytes_ = 40 * 1024;  // LDS ring of the DMA-staged gather (4 workgroups per CU)
+  int ring_bytes_ = 26 * 1024;  // LDS ring of the DMA-staged gather (6 workgroups per CU)
   bool use_dma_ = true;
+  int loader_waves_ = 1;
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
