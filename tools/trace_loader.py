@@ -7,6 +7,8 @@ t = t[t[:, 7] > 0]
 tot = (t[:, 7] - t[:, 0]) / 100.0
 w, b, i = t[:, 1] / 100.0, t[:, 2] / 100.0, t[:, 3] / 100.0
 nj, K = t[:, 4] // 1000, t[:, 4] % 1000
+cb, cw = t[:, 5] / 100.0, t[:, 6] / 100.0
+print("consumer wave 0: barrier-wait %.2f us, gather+store %.2f us (per workgroup)" % (cb.mean(), cw.mean()))
 print("workgroups", len(t), "mean total %.2f us; loader: vmcnt-wait %.2f  barrier-wait %.2f  dma-issue %.2f" % (tot.mean(), w.mean(), b.mean(), i.mean()))
 for k in sorted(set(K)):
     m = K == k

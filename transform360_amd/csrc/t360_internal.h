@@ -72,6 +72,9 @@ struct LowpassTile {
 // Tile kinds of the work list.
 enum : int {
   kTileStaged32 = 0,  // 32x32 output px, 4 px per lane, source box staged through LDS
+  kTileStrip128 = 3,  // 128x8 output px, 4 px per lane: ~330-byte source row fragments, which the
+                      // memory system streams at ~6 TB/s where 96-byte fragments reach ~3 TB/s
+                      // (tools/ubench/fragment_bw.hip)
   kTileStaged16 = 1,  // 16x16 output px, 1 px per lane, source box staged through LDS
   kTileDirect16 = 2,  // 16x16 output px, gathers straight from global memory (box too large)
 };

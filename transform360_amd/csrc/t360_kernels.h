@@ -31,7 +31,8 @@ hipError_t launch_fill_plane(uint8_t* dst, int64_t frame_bytes, int w, int h, in
                              int nframes, hipStream_t stream);
 
 // ---- tile planning (t360_tiles.hip) ----
-// out: 30 ints per 32x32 macro tile (5 boxes x {minx, maxx, minx_shifted, maxx_shifted, miny, maxy})
+// out: kScanBoxes*6 ints per 128x32 macro region ({minx, maxx, minx_shifted, maxx_shifted, miny, maxy} per box)
+constexpr int kScanBoxes = 24;
 hipError_t launch_tile_scan(const LutEntry* lut, int dw, int dh, int sw, int* out, hipStream_t stream);
 hipError_t launch_tile_lut(const LutEntry* lut, int dw, int dh, int sw, const TileDesc* tiles, int ntiles,
                            int halo, uint32_t* tlut, hipStream_t stream);

@@ -52,52 +52,90 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   const int halo_lo = ksize / 2 - 1, halo_hi = ksize / 2;
   int max_chunks = max_box_bytes / kStageChunk;
   if (max_chunks > 256 * kStageChunksPerLane) max_chunks = 256 * kStageChunksPerLane;
-  const int tiles_x = (dw + 31) / 32, tiles_y = (dh + 31) / 32;
-  const size_t nmacro = (size_t)tiles_x * tiles_y;
+  const int regions_x = (dw + 127) / 128, regions_y = (dh + 31) / 32;
+  const size_t nregions = (size_t)regions_x * regions_y;
+  const int per_region = kScanBoxes * 6;
 
   DeviceBuffer scan;
-  if (!scan.reserve(nmacro * 30 * sizeof(int))) return false;
+  if (!scan.reserve(nregions * per_region * sizeof(int))) return false;
   if (launch_tile_scan(d_lut, dw, dh, sw, scan.as<int>(), stream) != hipSuccess) return false;
-  std::vector<int> boxes(nmacro * 30);
+  std::vector<int> boxes(nregions * per_region);
   if (hipMemcpyAsync(boxes.data(), scan.as<void>(), boxes.size() * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
     return false;
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
 
   std::vector<TileDesc> tiles, direct;
-  tiles.reserve(nmacro);
+  tiles.reserve(nregions * 4);
   int64_t tlut_words = 0, staged_bytes = 0;
-  int n32 = 0, n16 = 0, ndirect = 0;
-  for (int ty = 0; ty < tiles_y; ty++)
-    for (int tx = 0; tx < tiles_x; tx++) {
-      const int* b = &boxes[((size_t)ty * tiles_x + tx) * 30];
-      const Box big = make_box(b, halo_lo, halo_hi, max_chunks);
-      if (big.empty) continue;
-      const int ox = tx * 32, oy = ty * 32;
-      auto emit = [&](const Box& bx, int kind, int tox, int toy, int edge) {
-        TileDesc t{};
-        t.ox = (int16_t)tox;
-        t.oy = (int16_t)toy;
-        t.kind = (int16_t)kind;
-        t.flags = (int16_t)((bx.seam_shift ? kTileSeamShift : 0) |
-                            ((tox + edge > dw || toy + edge > dh) ? kTilePartial : 0));
-        t.x0 = bx.x0;
-        t.y0 = bx.y0;
-        t.cpr = (int16_t)bx.cpr;
-        t.rows = (int16_t)bx.rows;
-        t.tlut = (int32_t)tlut_words;
-        if (kind == kTileStaged32) tlut_words += 1024, n32++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
-        else if (kind == kTileStaged16) tlut_words += 256, n16++, staged_bytes += (int64_t)bx.cpr * 16 * bx.rows;
-        else ndirect++;
-        (kind == kTileDirect16 ? direct : tiles).push_back(t);
-      };
-      if (big.fits) {
-        emit(big, kTileStaged32, ox, oy, 32);
+  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0;
+  // 128x8 strips give ~330-byte row fragments (better for HBM) but measured ~4 % slower end to end
+  // while the kernel is VALU-issue-bound; opt-in until that changes (DESIGN.md, round-1 notes)
+  const bool allow_strips = getenv("T360_STRIPS") != nullptr;
+  auto emit = [&](const Box& bx, int kind, int tox, int toy, int ew, int eh) {
+    TileDesc t{};
+    t.ox = (int16_t)tox;
+    t.oy = (int16_t)toy;
+    t.kind = (int16_t)kind;
+    t.flags = (int16_t)((bx.seam_shift ? kTileSeamShift : 0) | ((tox + ew > dw || toy + eh > dh) ? kTilePartial : 0));
+    t.x0 = bx.x0;
+    t.y0 = bx.y0;
+    t.cpr = (int16_t)bx.cpr;
+    t.rows = (int16_t)bx.rows;
+    t.tlut = (int32_t)tlut_words;
+    if (kind == kTileDirect16) {
+      ndirect++;
+      direct.push_back(t);
+      return;
+    }
+    tlut_words += kind == kTileStaged16 ? 256 : 1024;
+    staged_bytes += (int64_t)bx.cpr * kStageChunk * bx.rows;
+    (kind == kTileStaged16 ? n16 : kind == kTileStaged32 ? n32 : nstrip)++;
+    tiles.push_back(t);
+  };
+  for (int ry = 0; ry < regions_y; ry++)
+    for (int rx = 0; rx < regions_x; rx++) {
+      const int* b = &boxes[((size_t)ry * regions_x + rx) * per_region];
+      const int ox = rx * 128, oy = ry * 32;
+      // option A: four 128x8 strips (wide row fragments stream ~2x faster from HBM than the
+      // ~100-byte fragments of 32x32 tiles); option B: four 32x32 tiles with 16x16 fallback.
+      Box strip[4], tile[4];
+      bool strips_ok = allow_strips;
+      int64_t strip_bytes = 0, tile_bytes = 0;
+      for (int k = 0; k < 4; k++) {
+        strip[k] = make_box(b + 6 * k, halo_lo, halo_hi, max_chunks);
+        tile[k] = make_box(b + 6 * (4 + k), halo_lo, halo_hi, max_chunks);
+        if (!strip[k].empty) {
+          strips_ok = strips_ok && strip[k].fits;
+          strip_bytes += (int64_t)strip[k].cpr * kStageChunk * strip[k].rows;
+        }
+        if (!tile[k].empty) {
+          if (tile[k].fits) {
+            tile_bytes += (int64_t)tile[k].cpr * kStageChunk * tile[k].rows;
+          } else {
+            for (int qd = 0; qd < 4; qd++) {
+              const Box sub = make_box(b + 6 * (8 + 4 * k + qd), halo_lo, halo_hi, max_chunks);
+              if (!sub.empty) tile_bytes += sub.fits ? (int64_t)sub.cpr * kStageChunk * sub.rows : (int64_t)1 << 20;
+            }
+          }
+        }
+      }
+      // strips win unless they stage clearly more bytes (curved rows on the polar faces)
+      if (strips_ok && strip_bytes * 2 <= tile_bytes * 3) {
+        for (int k = 0; k < 4; k++)
+          if (!strip[k].empty) emit(strip[k], kTileStrip128, ox, oy + 8 * k, 128, 8);
         continue;
       }
-      for (int qd = 0; qd < 4; qd++) {
-        const Box sub = make_box(b + 6 * (1 + qd), halo_lo, halo_hi, max_chunks);
-        if (sub.empty) continue;
-        emit(sub, sub.fits ? kTileStaged16 : kTileDirect16, ox + (qd & 1) * 16, oy + (qd >> 1) * 16, 16);
+      for (int k = 0; k < 4; k++) {
+        if (tile[k].empty) continue;
+        if (tile[k].fits) {
+          emit(tile[k], kTileStaged32, ox + 32 * k, oy, 32, 32);
+          continue;
+        }
+        for (int qd = 0; qd < 4; qd++) {
+          const Box sub = make_box(b + 6 * (8 + 4 * k + qd), halo_lo, halo_hi, max_chunks);
+          if (sub.empty) continue;
+          emit(sub, sub.fits ? kTileStaged16 : kTileDirect16, ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, 16, 16);
+        }
       }
     }
   if (tiles.size() > 0x7fffffff || tlut_words > 0x7fffffff) return false;
@@ -117,14 +155,16 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
   plan->ntiles = (int)nstaged;
   plan->n32 = n32;
+  plan->nstrip = nstrip;
   plan->n16 = n16;
   plan->ndirect = ndirect;
   plan->staged_bytes = staged_bytes;
   plan->valid = true;
   if (getenv("T360_VERBOSE"))
-    printf("transform360: gather plan %dx%d <- %dx%d: %d tiles (%d staged 32x32, %d staged 16x16, %d direct), "
-           "%.2f MB staged per plane (%.2fx the source plane)\n",
-           dw, dh, sw, sh, plan->ntiles, n32, n16, ndirect, staged_bytes / 1e6, (double)staged_bytes / ((double)sw * sh));
+    printf("transform360: gather plan %dx%d <- %dx%d: %d staged tiles (%d strips 128x8, %d tiles 32x32, %d tiles 16x16) + "
+           "%d direct, %.2f MB staged per plane (%.2fx the source plane)\n",
+           dw, dh, sw, sh, plan->ntiles, nstrip, n32, n16, ndirect, staged_bytes / 1e6,
+           (double)staged_bytes / ((double)sw * sh));
   return true;
 }
 

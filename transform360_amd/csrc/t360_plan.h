@@ -14,7 +14,7 @@ namespace t360 {
 struct GatherPlan {
   bool valid = false;
   int ntiles = 0;            // staged tiles (first in `tiles`); the ndirect direct tiles follow them
-  int n32 = 0, n16 = 0, ndirect = 0;
+  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0;
   int64_t staged_bytes = 0;  // sum of staged box bytes over the plane (L2 -> LDS traffic per frame)
   DeviceBuffer tiles;        // TileDesc[ntiles]
   DeviceBuffer tlut;         // box-relative LUT words

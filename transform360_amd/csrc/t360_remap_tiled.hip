@@ -162,7 +162,9 @@ __device__ __forceinline__ size_t out_pos(const TiledPlane& pl, const TileDesc& 
   const int tid = threadIdx.x;
   int ox, oy;
   if (NPX == 4) {
-    const int x = tid & 31, band = tid >> 5;
+    // 32x32 tile: 32 columns x 8 bands of 4 rows; 128x8 strip: 128 columns x 2 bands of 4 rows
+    const int logw = t.kind == kTileStrip128 ? 7 : 5;
+    const int x = tid & ((1 << logw) - 1), band = tid >> logw;
     if (dword_store) {
       ox = t.ox + (x & ~3);
       oy = t.oy + band * 4 + (x & 3);
@@ -340,7 +342,7 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
     a.trace[wg * 8 + 3] = acc_issue;  // loader: total time issuing DMA
     a.trace[wg * 8 + 4] = (unsigned long long)(nj * 1000 + K);
   }
-  if (which == 0) trace_mark(a, 6);
+  if (which == 0 && !(a.debug & (32 | 16))) trace_mark(a, 6);
 }
 
 template <int NPX>
@@ -358,15 +360,29 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
   const uint8_t* __restrict__ box = lds;
   const uint8_t* const ring_end = lds + g.K * g.slot_bytes;
   const int nf = f1 - f0;
+  unsigned long long acc_bar = 0, acc_work = 0;
+  const bool tracing = a.trace != nullptr && (a.debug & 16);
   for (int i = 0; i < nf; i++) {
+    unsigned long long c0 = tracing ? wall_clock64() : 0;
     frame_barrier();
+    unsigned long long c1 = tracing ? wall_clock64() : 0;
     if (!(a.debug & 8)) gather_store<NPX>(px, box, g.pitch, d, pl.dstride, dword_store);
+    if (tracing) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      acc_bar += c1 - c0;
+      acc_work += wall_clock64() - c1;
+    }
     d += pl.dst_frame_bytes;
     box += g.slot_bytes;
     if (box == ring_end) box = lds;
-    if (i == 0 && threadIdx.x < 64) trace_mark(a, 5);
+    if (i == 0 && threadIdx.x < 64 && !tracing) trace_mark(a, 5);
   }
   if (threadIdx.x < 64) trace_mark(a, 7);
+  if (tracing && threadIdx.x == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    a.trace[wg * 8 + 5] = acc_bar;   // consumer wave 0: total time at the frame barrier
+    a.trace[wg * 8 + 6] = acc_work;  // consumer wave 0: total gather + store issue time
+  }
 }
 
 __global__ __launch_bounds__(512, 1) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
@@ -392,12 +408,18 @@ __global__ __launch_bounds__(512, 1) void remap_tiled_cubic_dma_kernel(TiledArgs
   const int f1 = min(f0 + a.frames_per_block, a.nframes);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave == 0) trace_mark(a, 0);
+  if (a.trace && (a.debug & 32) && threadIdx.x == 0) {  // where did this workgroup run?
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
   if (wave >= kLoaderWave) {
     loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
-  } else if (t.kind == kTileStaged32) {
-    consumer_waves<4>(a, pl, t, lds, f0, f1);
-  } else {
+  } else if (t.kind == kTileStaged16) {
     consumer_waves<1>(a, pl, t, lds, f0, f1);
+  } else {
+    consumer_waves<4>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
   }
 }
 
@@ -491,10 +513,10 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_regs_kernel(TiledArgs a
   const TileDesc t = pl.tiles[xcd_contiguous(blockIdx.x, pl.ntiles)];
   const int f0 = blockIdx.y * a.frames_per_block;
   const int f1 = min(f0 + a.frames_per_block, a.nframes);
-  if (t.kind == kTileStaged32)
-    staged_tile_regs<4>(a, pl, t, lds, f0, f1);
-  else
+  if (t.kind == kTileStaged16)
     staged_tile_regs<1>(a, pl, t, lds, f0, f1);
+  else
+    staged_tile_regs<4>(a, pl, t, lds, f0, f1);
 }
 
 // ===================== tiles too large to stage: direct gather ================================

@@ -27,26 +27,32 @@ __device__ __forceinline__ void box_init(int* b) {
 
 }  // namespace
 
-// out[tile][box 0..4][6]: box 0 = whole 32x32 macro tile, 1..4 = quadrants (row-major)
+// One workgroup per 128x32 output macro region.  out[region][box 0..23][6]:
+//   box 0..3   the four 128x8 strips (top to bottom)
+//   box 4..7   the four 32x32 tiles (left to right)
+//   box 8..23  the sixteen 16x16 quadrants: 8 + 4*tile + quadrant (quadrant row-major in its tile)
 __global__ __launch_bounds__(256) void tile_scan_kernel(const LutEntry* __restrict__ lut, int dw, int dh, int sw,
-                                                        int tiles_x, int* __restrict__ out) {
-  __shared__ int box[5][6];
+                                                        int regions_x, int* __restrict__ out) {
+  __shared__ int box[kScanBoxes][6];
   const int tid = threadIdx.x;
-  if (tid < 5) box_init(box[tid]);
+  if (tid < kScanBoxes) box_init(box[tid]);
   __syncthreads();
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int lx = (tid & 7) * 4, ly = tid >> 3;  // 8 lanes x 4 px wide, 32 rows
-  const int oy = ty * 32 + ly;
-  if (oy < dh) {
-    for (int p = 0; p < 4; p++) {
-      const int ox = tx * 32 + lx + p;
-      if (ox >= dw) break;
+  const int rx = blockIdx.x % regions_x, ry = blockIdx.x / regions_x;
+  // lane = (column within the region, band of 16 rows); 16 pixels per lane
+  const int lx = tid & 127, band = tid >> 7;
+  const int ox = rx * 128 + lx;
+  if (ox < dw) {
+    for (int k = 0; k < 16; k++) {
+      const int ly = band * 16 + k;
+      const int oy = ry * 32 + ly;
+      if (oy >= dh) break;
       const LutEntry e = lut[(size_t)oy * dw + ox];
       const int x = e.ix, y = e.iy;
       const int xs = x >= (sw >> 1) ? x - sw : x;
-      const int quad = 1 + ((ly >> 4) << 1) + ((lx + p) >> 4);
-      for (int b = 0; b < 2; b++) {
-        int* B = box[b ? quad : 0];
+      const int tile = lx >> 5;
+      const int ids[3] = {ly >> 3, 4 + tile, 8 + 4 * tile + ((ly >> 4) << 1) + ((lx & 31) >> 4)};
+      for (int b = 0; b < 3; b++) {
+        int* B = box[ids[b]];
         atomicMin(&B[0], x);
         atomicMax(&B[1], x);
         atomicMin(&B[2], xs);
@@ -57,12 +63,12 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const LutEntry* __restri
     }
   }
   __syncthreads();
-  if (tid < 30) out[(size_t)blockIdx.x * 30 + tid] = box[tid / 6][tid % 6];
+  if (tid < kScanBoxes * 6) out[(size_t)blockIdx.x * (kScanBoxes * 6) + tid] = box[tid / 6][tid % 6];
 }
 
 hipError_t launch_tile_scan(const LutEntry* lut, int dw, int dh, int sw, int* out, hipStream_t stream) {
-  const int tiles_x = (dw + 31) / 32, tiles_y = (dh + 31) / 32;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, stream, lut, dw, dh, sw, tiles_x, out);
+  const int regions_x = (dw + 127) / 128, regions_y = (dh + 31) / 32;
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(regions_x * regions_y), dim3(256), 0, stream, lut, dw, dh, sw, regions_x, out);
   return hipGetLastError();
 }
 
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void tile_lut_kernel(const LutEntry* __restric
   const TileDesc t = tiles[blockIdx.x];
   if (t.kind == kTileDirect16) return;  // the direct path reads the absolute LUT
   const int tid = threadIdx.x;
-  const int npx = t.kind == kTileStaged32 ? 4 : 1;
+  const int npx = t.kind == kTileStaged16 ? 1 : 4;
   for (int p = 0; p < npx; p++) {
     int ox, oy;
     if (t.kind == kTileStaged32) {
@@ -83,6 +89,9 @@ __global__ __launch_bounds__(256) void tile_lut_kernel(const LutEntry* __restric
       // source-row neighbourhood per instruction (conflict-free ds_read2_b32, see the gather)
       ox = t.ox + (tid & 31);
       oy = t.oy + (tid >> 5) * 4 + p;
+    } else if (t.kind == kTileStrip128) {
+      ox = t.ox + (tid & 127);
+      oy = t.oy + (tid >> 7) * 4 + p;
     } else {
       ox = t.ox + (tid & 15);
       oy = t.oy + (tid >> 4);

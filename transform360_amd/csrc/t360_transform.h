@@ -105,7 +105,8 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  int ring_bytes_ = 26 * 1024;  // LDS ring of the DMA-staged gather (6 workgroups per CU)
+  int ring_bytes_ = 48 * 1024;  // LDS ring of the DMA-staged gather: 3 workgroups per CU are resident
+                                // (VGPR-limited, measured), 3 x 48 KiB fits the 160 KiB LDS
   bool use_dma_ = true;
   int loader_waves_ = 1;
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
