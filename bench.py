@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 
 stream of 3840x1920 8-bit yuv420p equirect frames -> 512-edge CUBEMAP_32 (1536x1024), bicubic,
 low-pass off.  Frames are counter-hash noise generated on the device and RESIDENT IN HBM before
 the timed region starts; one "step" is one pass of the hot path (all three planes) over one batch
-of F frames (default 32: 354 MB of input, larger than the 256 MB Infinity Cache).
+of F frames (default 64: 708 MB of input, far larger than the 256 MB Infinity Cache).
 
 Multi-GPU (--gpus N under torch.distributed.run): whole frames are sharded across ranks --
 rank r owns frames r*F .. r*F+F-1 of every step (weak scaling, no data-path collective).  RCCL
@@ -66,8 +66,8 @@ def cpu_baseline(wl, lin, lout, budget_s):
     from transform360_amd.handler import frame_seed, noise_bytes
     T = os.cpu_count() or 1
     ctx = filter_defaults(**wl["ov"])
-    o = O.Oracle(ctx, threads=T)
     t0 = time.perf_counter()
+    o = O.Oracle(ctx, threads=T)
     for idx, k in ((0, 0), (1, 1)):
         assert o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
     init_s = time.perf_counter() - t0
@@ -78,22 +78,26 @@ def cpu_baseline(wl, lin, lout, budget_s):
         for p in range(3):
             assert o.transformFramePlane(lin.plane_view(frame, p), outs[p], 1 if p else 0, p)
 
-    one_frame()  # warm (tables, page faults)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one_frame()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 64:
-            break
-    fps = n / el
-    o1 = O.Oracle(ctx, threads=1)
-    for idx, k in ((0, 0), (1, 1)):
-        assert o1.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
-    t0 = time.perf_counter()
-    for p in range(3):
-        assert o1.transformFramePlane(lin.plane_view(frame, p), outs[p], 1 if p else 0, p)
-    fps1 = 1.0 / (time.perf_counter() - t0)
+    def timed(threads, seconds):
+        o.set_threads(threads)
+        one_frame()  # warm (tables, page faults, worker pool)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one_frame()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                return n / el, n, el
+
+    # T = hardware_concurrency is what the reference gets (cv::parallel_for_ + one std::thread per
+    # segment); also try fewer threads, the striped remap of one 4K plane does not scale to
+    # hundreds of cores.  The best of the sweep is reported, with its thread count.
+    sweep = sorted({T, min(T, 64), min(T, 16), 1}, reverse=True)
+    per = budget_s / (len(sweep) + 0.5)
+    results = {th: timed(th, per if th > 1 else per / 2) for th in sweep}
+    best_t = max(results, key=lambda th: results[th][0])
+    fps, n, el = results[best_t]
+    fps1 = results[1][0]
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -105,11 +109,12 @@ def cpu_baseline(wl, lin, lout, budget_s):
         pass
     mpix = lout.dims[0][0] * lout.dims[0][1] / 1e6
     return {
-        "value": round(fps * mpix, 3), "unit": "Mpix/s", "cores": T, "kind": "port",
-        "sample": "%d frames of the same workload in %.1f s on %d threads (oracle = restatement of the "
-                  "reference's OpenCV path, not linked OpenCV); 1 thread: %.3f Mpix/s; map init %.2f s"
-                  % (n, el, T, fps1 * mpix, init_s),
-        "cpu_model": model, "fps": round(fps, 3), "value_1thread": round(fps1 * mpix, 3),
+        "value": round(fps * mpix, 3), "unit": "Mpix/s", "cores": best_t, "kind": "port",
+        "sample": "%d frames of the same workload in %.1f s on %d threads, the best of a thread sweep %s on a host "
+                  "with %d logical cores (oracle = restatement of the reference's OpenCV path, not linked OpenCV); "
+                  "map init %.2f s" % (n, el, best_t,
+                                        {th: round(r[0] * mpix, 1) for th, r in sorted(results.items())}, T, init_s),
+        "cpu_model": model, "host_cores": T, "fps": round(fps, 3), "value_1thread": round(fps1 * mpix, 3),
     }
 
 
@@ -118,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (BASELINE config 5: 64)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

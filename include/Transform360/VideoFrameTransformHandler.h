@@ -30,8 +30,14 @@
 extern "C" {
 #endif
 
-/* Opaque to C callers; the C++ class lives inside the library. */
+/* Opaque to C callers; the C++ class lives inside the library.  The reference spells this
+ * `typedef class VideoFrameTransform VideoFrameTransform;` for both languages (Handler.h:22),
+ * which a C compiler rejects; the C branch below is the same incomplete type. */
+#ifdef __cplusplus
 typedef class VideoFrameTransform VideoFrameTransform;
+#else
+typedef struct VideoFrameTransform VideoFrameTransform;
+#endif
 
 /* reference Handler.h:24 / Handler.cpp:18-20 */
 extern VideoFrameTransform* VideoFrameTransform_new(FrameTransformContext* ctx);

@@ -288,3 +288,45 @@ def test_error_convention(T, gpu_lib):
         dst = dev(np.full((32, 48), 9, np.uint8))
         assert t.transformFramePlane(dev(np.zeros((64, 128), np.uint8)), dst, 0)
         assert (dst == 9).all().item()
+
+
+# ---------------------------------------------------------------- plain-C caller (ffmpeg stand-in)
+def test_c_harness_replays_filter_sequence(T, oracle_mod, tmp_path):
+    """tests/c/vf_sequence.c links against libTransform360.so like ffmpeg would
+    (--extra-libs='-lTransform360 -lstdc++', reference README.md:67) and replays
+    vf_transform360.c's call sequence with malloc'd frames and padded linesizes."""
+    import os
+    import subprocess
+
+    from tests.conftest import ROOT
+    from transform360_amd import _lib
+    O = oracle_mod
+    exe = tmp_path / "vf_sequence"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "vf_sequence.c"), "-o", str(exe), "-L", libdir,
+                           "-lTransform360", "-lstdc++", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    in_w, in_h, edge, nframes = 1280, 640, 260, 2          # 260 -> 256 (multiple of 16)
+    for interp, lowpass in ((CUBIC, 1), (NEAREST, 0)):
+        out = subprocess.check_output([str(exe), str(in_w), str(in_h), str(edge), str(interp), str(lowpass),
+                                       str(nframes)]).decode()
+        lines = [l.split() for l in out.splitlines() if l.startswith("frame")]
+        assert len(lines) == nframes * 3, out
+        ctx = filter_defaults(interpolation_alg=interp, enable_low_pass_filter=lowpass, num_vertical_segments=15,
+                              num_horizontal_segments=32)
+        o = O.Oracle(ctx, threads=4)
+        out_w, out_h = 768, 512
+        cw, ch = chroma_dims(in_w, in_h)
+        ocw, och = chroma_dims(out_w, out_h)
+        assert o.generateMapForPlane(in_w, in_h, out_w, out_h, 0) and o.generateMapForPlane(cw, ch, ocw, och, 1)
+        for l in lines:
+            f, plane = int(l[1]), int(l[3])
+            iw, ih, ow, oh = (in_w, in_h, out_w, out_h) if plane == 0 else (cw, ch, ocw, och)
+            ls = (iw + 63) // 64 * 64 + 64
+            seed = 0x360 ^ (f << 40) ^ (plane << 36)
+            src = T.noise_bytes(ls * ih, seed).reshape(ih, ls)[:, :iw]
+            want = np.zeros((oh, ow), np.uint8)
+            assert o.transformFramePlane(src, want, 1 if plane else 0, plane)
+            assert l[4] == "%dx%d" % (ow, oh)
+            assert l[6] == hx(O.fnv1a64(want)), "frame %d plane %d differs from the oracle" % (f, plane)
+            assert l[8] == "intact"

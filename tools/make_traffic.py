@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (tools/prof_pmc.sh
+with PMC_MEM=1), for bench.py's roofline.traffic field.
+
+Uses the L2's memory-side request counters by size, which need no unit correction:
+  read  bytes = 32*TCC_EA0_RDREQ_32B + 64*TCC_EA0_RDREQ_64B + 128*TCC_EA0_RDREQ_128B
+  write bytes = 64*TCC_EA0_WRREQ_64B + 32*(TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B)
+(cross-check: FETCH_SIZE [KiB] * 2, the gfx950 correction of MI355X_MICROARCH.md "HBM", agrees
+with the read figure to <1 % on this kernel).
+
+usage: make_traffic.py <pmc_dir> <config> <frames> <out.json>
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+pmc, config, frames, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(os.path.join(pmc, "*", "*counter_collection.csv")):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+name = max((k for k in acc if "remap_tiled_cubic_dma_kernel" in k or "remap_gather_kernel" in k),
+           key=lambda k: sum(acc[k].get("TCC_EA0_RDREQ_sum", [0])), default=None)
+if name is None:
+    sys.exit("no gather kernel found in %s" % pmc)
+m = {k: sum(v) / len(v) for k, v in acc[name].items()}
+rd = 32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * m.get("TCC_EA0_RDREQ_128B_sum", 0)
+wr = 64 * m.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (m.get("TCC_EA0_WRREQ_sum", 0) - m.get("TCC_EA0_WRREQ_64B_sum", 0))
+res = {"config": config, "frames": frames, "kernel": name.split("(")[0],
+       "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
+       "hbm_bytes_per_launch": int(rd + wr),
+       "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),
+       "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum, mean over dispatches"}
+with open(out, "w") as f:
+    json.dump(res, f, indent=1)
+    f.write("\n")
+print(json.dumps(res))
