@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -30,7 +31,7 @@ if name is None:
 m = {k: sum(v) / len(v) for k, v in acc[name].items()}
 rd = 32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * m.get("TCC_EA0_RDREQ_128B_sum", 0)
 wr = 64 * m.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (m.get("TCC_EA0_WRREQ_sum", 0) - m.get("TCC_EA0_WRREQ_64B_sum", 0))
-res = {"config": config, "frames": frames, "kernel": name.split("(")[0],
+res = {"config": config, "frames": frames, "kernel": (re.search(r"(\w+_kernel)", name).group(1) if re.search(r"(\w+_kernel)", name) else name),
        "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
        "hbm_bytes_per_launch": int(rd + wr),
        "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),

@@ -3,6 +3,7 @@
 every counter over its dispatches (counter_collection.csv: one row per dispatch per counter)."""
 import csv
 import glob
+import re
 import os
 import sys
 from collections import defaultdict
@@ -15,7 +16,8 @@ for path in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
             name = row.get("Kernel_Name", "")
             if "t360" not in name:
                 continue
-            short = name.split("(")[0].split("::")[-1]
+            m = re.search(r"(\w+_kernel)", name)
+            short = m.group(1) if m else name.split("(")[0].split("::")[-1]
             key = (short, row.get("Grid_Size", ""), row.get("VGPR_Count", row.get("Arch_VGPR_Count", "")),
                    row.get("LDS_Block_Size", ""), row.get("Scratch_Size", ""))
             acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -51,7 +51,7 @@ struct TiledPlane {
   int ntiles;
   int dst_dword_ok;         // plane base, stride and frame distance are 4-byte aligned: dword stores
   int src_vec_ok;           // ... 16-byte aligned and sw % 16 == 0: every staged chunk is one dwordx4
-  int pad;
+  int ndirect;              // kTileDirect16 descriptors stored behind the ntiles staged ones
 };
 struct TiledArgs {
   const int16_t* wtab;      // OpenCV Q15 table (direct tiles)
@@ -68,9 +68,8 @@ struct TiledArgs {
 };
 // Fused launch over all planes; every plane must have src_vec_ok (chunks go global -> LDS by DMA).
 hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream);
-// Direct (unstaged) tiles of one plane: `tiles` holds ntiles kTileDirect16 descriptors.
-hipError_t launch_remap_direct_cubic(const TiledPlane& pl, const TileDesc* tiles, int ntiles, const int16_t* wtab,
-                                     int nframes, hipStream_t stream);
+// Direct (unstaged) tiles of all planes in `a` (plane[k].tiles + ntiles, ndirect of them): one launch.
+hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream);
 // One plane, chunks staged through registers (any alignment / width).
 hipError_t launch_remap_tiled_cubic_regs(const TiledArgs& a, hipStream_t stream);
 

@@ -523,24 +523,38 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_regs_kernel(TiledArgs a
 // The few 16x16 tiles around each pole whose source box exceeds the staging budget (they span a
 // full quadrant of longitudes): one workgroup per (tile, frame), one pixel per
 // lane, 16 independent byte loads in flight per lane.
-__global__ __launch_bounds__(256) void remap_direct_cubic_kernel(TiledPlane pl, const TileDesc* __restrict__ tiles,
-                                                                 const int16_t* __restrict__ wtab) {
-  const TileDesc t = tiles[blockIdx.x];
+__global__ __launch_bounds__(256) void remap_direct_cubic_kernel(TiledArgs a) {
+  int b = blockIdx.x;
+  TiledPlane pl = a.plane[0];
+  if (a.nplanes > 1 && b >= pl.ndirect) {
+    b -= pl.ndirect;
+    pl = a.plane[1];
+    if (a.nplanes > 2 && b >= pl.ndirect) {
+      b -= pl.ndirect;
+      pl = a.plane[2];
+      if (a.nplanes > 3 && b >= pl.ndirect) {
+        b -= pl.ndirect;
+        pl = a.plane[3];
+      }
+    }
+  }
+  const TileDesc t = pl.tiles[pl.ntiles + b];
   const int tid = threadIdx.x;
   const int ox = t.ox + (tid & 15), oy = t.oy + (tid >> 4);
   if (ox >= pl.dw || oy >= pl.dh) return;
   const int f = blockIdx.y;
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
-  const int v = sample<4, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, wtab, e);
+  const int v = sample<4, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
   pl.dst[(size_t)f * pl.dst_frame_bytes + (size_t)oy * pl.dstride + ox] = (uint8_t)v;
 }
 
 }  // namespace
 
-hipError_t launch_remap_direct_cubic(const TiledPlane& pl, const TileDesc* tiles, int ntiles, const int16_t* wtab,
-                                     int nframes, hipStream_t stream) {
-  if (ntiles <= 0 || nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(remap_direct_cubic_kernel, dim3(ntiles, nframes, 1), dim3(256), 0, stream, pl, tiles, wtab);
+hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream) {
+  int total = 0;
+  for (int k = 0; k < a.nplanes; k++) total += a.plane[k].ndirect;
+  if (total <= 0 || a.nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(remap_direct_cubic_kernel, dim3(total, a.nframes, 1), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -175,6 +175,12 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     return;
   }
   stream_ = own_stream_;
+  if (hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&fork_event_, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&join_event_, hipEventDisableTiming) != hipSuccess) {
+    printf("transform360: could not create the auxiliary stream (%s)\n", hipGetErrorString(hipGetLastError()));
+    return;
+  }
   if (const char* e = getenv("T360_RING_KB")) {
     const int v = atoi(e);
     if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
@@ -195,6 +201,12 @@ VideoFrameTransform::~VideoFrameTransform() {
   if (!ok_) return;
   DeviceGuard g(device_);
   (void)hipStreamSynchronize(stream_);
+  if (aux_stream_) {
+    (void)hipStreamSynchronize(aux_stream_);
+    (void)hipStreamDestroy(aux_stream_);
+  }
+  if (fork_event_) (void)hipEventDestroy(fork_event_);
+  if (join_event_) (void)hipEventDestroy(join_event_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -554,6 +566,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   fused.loader_waves = loader_waves_;
   fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
   const bool multi = n_frames > 1;
+  TiledArgs direct = fused;  // the pole tiles too large to stage, all planes in one small launch
   for (int k = 0; k < njobs; k++) {
     const PlaneJob& j = jobs[k];
     PlaneState& p = planes_[j.idx];
@@ -584,10 +597,8 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
                         (!multi || (j.out_frame_bytes & 3) == 0);
       tp.src_vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
                       (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
-      if (p.plan.ndirect > 0 &&
-          !check(launch_remap_direct_cubic(tp, tp.tiles + tp.ntiles, p.plan.ndirect, weights_.as<int16_t>(), n_frames,
-                                           stream_), "direct tiles launch"))
-        return false;
+      tp.ndirect = p.plan.ndirect;
+      if (tp.ndirect > 0 && direct.nplanes < 4) direct.plane[direct.nplanes++] = tp;
       if (tp.src_vec_ok && use_dma_ && fused.nplanes < 4) {
         fused.plane[fused.nplanes++] = tp;
         fused.total_tiles += tp.ntiles;
@@ -617,6 +628,15 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
     if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
   }
+  if (direct.nplanes > 0) {
+    // fork: the direct tiles write pixels no staged tile writes, so they run beside the main
+    // gather on the handle's auxiliary stream and join before the call's work is complete
+    if (!check(hipEventRecord(fork_event_, stream_), "hipEventRecord") ||
+        !check(hipStreamWaitEvent(aux_stream_, fork_event_, 0), "hipStreamWaitEvent") ||
+        !check(launch_remap_direct_cubic(direct, aux_stream_), "direct tiles launch") ||
+        !check(hipEventRecord(join_event_, aux_stream_), "hipEventRecord"))
+      return false;
+  }
   if (fused.nplanes > 0) {
     const char* trace_path = getenv("T360_TRACE");  // schedule debugging: dump per-workgroup timestamps
     t360::DeviceBuffer trace;
@@ -640,6 +660,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       }
     }
   }
+  if (direct.nplanes > 0 && !check(hipStreamWaitEvent(stream_, join_event_, 0), "hipStreamWaitEvent")) return false;
   return true;
 }
 

@@ -101,6 +101,8 @@ class VideoFrameTransform {
   int device_ = 0;
   hipStream_t own_stream_ = nullptr;
   hipStream_t stream_ = nullptr;
+  hipStream_t aux_stream_ = nullptr;  // direct (unstaged) pole tiles run here beside the main gather
+  hipEvent_t fork_event_ = nullptr, join_event_ = nullptr;
   PlaneState planes_[t360::kMaxMaps];
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
