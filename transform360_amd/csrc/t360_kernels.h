@@ -63,6 +63,7 @@ struct TiledArgs {
   int ring_bytes;           // LDS ring of the DMA-staged kernel
   int loader_waves;         // DMA loader waves per workgroup (1..4) next to the 4 consumer waves
   int debug;                // experiments (T360_DEBUG): bit2 no steady-state DMA, bit3 no gather
+  int variant;              // DMA kernel build: bit0 LDS reads in groups of 2 px, bit1 register cap for 6 waves/SIMD
   unsigned long long* trace;  // optional: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   TiledPlane plane[4];
 };

@@ -50,7 +50,7 @@ struct PixelSetup {
 
 template <int NPX>
 __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t* __restrict__ wpack,
-                                            const TileDesc& t, int pitch, PixelSetup<NPX>& s) {
+                                            const TileDesc& t, int pitch, PixelSetup<NPX>& s, int debug = 0) {
   const int tid = threadIdx.x;
   uint32_t words[4];
   if (NPX == 4) {
@@ -63,7 +63,7 @@ __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t
   for (int p = 0; p < NPX; p++) {
     const uint32_t e = words[p];
     s.live[p] = (e >> 31) == 0;
-    const int rx = e & 1023, ry = (e >> 10) & 255, frac = (e >> 18) & 1023;
+    const int rx = e & 1023, ry = (e >> 10) & 255, frac = (debug & 128) ? 0 : (e >> 18) & 1023;
     s.off[p] = s.live[p] ? ry * pitch + rx : 0;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(wpack + (size_t)frac * kCubicPackDwords);
     const uint4 h = wp[0], l = wp[1];
@@ -90,43 +90,50 @@ __device__ __forceinline__ void pin_pixels(PixelSetup<NPX>& s) {
   }
 }
 
-// one frame of one tile: gather from the staged box at `box`, write the output pixels
-template <int NPX>
+// one frame of one tile: gather from the staged box at `box`, write the output pixels.
+// GROUP = pixels whose LDS reads are in flight together: 4 -> one LDS round trip per frame and
+// 32 VGPRs of read data; 2 -> two round trips, 16 VGPRs (fits 6 waves per SIMD).
+// (Unaligned ds_read_b32 windows were measured 2.8x SLOWER than aligned ds_read2_b32 + v_alignbit
+// on gfx950, so the window is always assembled from two aligned dwords.)
+template <int NPX, int GROUP>
 __device__ __forceinline__ void gather_store(const PixelSetup<NPX>& s, const uint8_t* __restrict__ box, int pitch,
                                              uint8_t* __restrict__ d, int dstride, bool dword_store) {
-  // Phase 1: every LDS read of the frame in flight at once (16 ds_read2_b32 for 4 pixels) --
-  // one LDS round trip per frame instead of one per pixel; phase 2: the dot products.
-  uint32_t lo32[NPX][4], hi32[NPX][4];
-#pragma unroll
-  for (int p = 0; p < NPX; p++) {
-    const int a4 = s.off[p] & ~3;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
-      lo32[p][r] = q[0];
-      hi32[p][r] = q[1];
-    }
-  }
-  // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
-#pragma unroll
-  for (int p = 0; p < NPX; p++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(lo32[p][r]), "+v"(hi32[p][r]));
-  }
+  constexpr int G = GROUP < NPX ? GROUP : NPX;
   int v[NPX];
 #pragma unroll
-  for (int p = 0; p < NPX; p++) {
-    const uint32_t sh = (uint32_t)(s.off[p] & 3) * 8u;
-    int hi = 0;
-    uint32_t lo = (uint32_t)s.bias[p];
+  for (int p0 = 0; p0 < NPX; p0 += G) {
+    // Phase 1: the group's LDS reads in flight at once; phase 2: the dot products.
+    uint64_t win[G][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t px4 = __builtin_amdgcn_alignbit(hi32[p][r], lo32[p][r], sh);  // 4 consecutive source bytes
-      hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[p][r], hi, false);
-      lo = __builtin_amdgcn_udot4(px4, s.wl[p][r], lo, false);
+    for (int p = 0; p < G; p++) {
+      const int a4 = s.off[p0 + p] & ~3;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
+        win[p][r] = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+      }
     }
-    const int sum = (hi << 8) + (int)lo;  // = SUM p*w + 16384
-    v[p] = sat_u8(sum >> kCoefBits);
+    // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) asm volatile("" : "+v"(win[p][r]));
+    }
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      const uint32_t sh = (uint32_t)(s.off[p0 + p] & 3) * 8u;
+      int hi = 0;
+      uint32_t lo = (uint32_t)s.bias[p0 + p];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        // 4 consecutive source bytes out of the aligned 8-byte window
+        const uint32_t px4 = __builtin_amdgcn_alignbit((uint32_t)(win[p][r] >> 32), (uint32_t)win[p][r], sh);
+        hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[p0 + p][r], hi, false);
+        lo = __builtin_amdgcn_udot4(px4, s.wl[p0 + p][r], lo, false);
+      }
+      const int sum = (hi << 8) + (int)lo;  // = SUM p*w + 16384
+      v[p0 + p] = sat_u8(sum >> kCoefBits);
+    }
   }
   if (NPX == 4) {
     // v[k] is the pixel of column x = lane & 31 in row 4*(lane >> 5) + k of the tile.
@@ -208,53 +215,63 @@ __device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
 }
 constexpr int kMaxLoaderInstr = kStageChunksPerLane * 4;  // 16 x (64 lanes x 16 B) = 16 KiB box
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate, max 63)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction only takes an immediate):
+// a computed jump into a table of 8-byte entries {s_waitcnt vmcnt(k); s_branch out}.  Two taken
+// branches per call; a switch() compiles to a ~12-branch decision tree, which is measurable in a
+// loop whose whole body is a few hundred nanoseconds.
 __device__ __forceinline__ void wait_vmcnt(int n) {
-  switch (n) {
-#define T360_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    T360_W(0) T360_W(1) T360_W(2) T360_W(3) T360_W(4) T360_W(5) T360_W(6) T360_W(7)
-    T360_W(8) T360_W(9) T360_W(10) T360_W(11) T360_W(12) T360_W(13) T360_W(14) T360_W(15)
-    T360_W(16) T360_W(17) T360_W(18) T360_W(19) T360_W(20) T360_W(21) T360_W(22) T360_W(23)
-    T360_W(24) T360_W(25) T360_W(26) T360_W(27) T360_W(28) T360_W(29) T360_W(30) T360_W(31)
-    T360_W(32) T360_W(33) T360_W(34) T360_W(35) T360_W(36) T360_W(37) T360_W(38) T360_W(39)
-    T360_W(40) T360_W(41) T360_W(42) T360_W(43) T360_W(44) T360_W(45) T360_W(46) T360_W(47)
-    T360_W(48) T360_W(49) T360_W(50) T360_W(51) T360_W(52) T360_W(53) T360_W(54) T360_W(55)
-    T360_W(56) T360_W(57) T360_W(58) T360_W(59) T360_W(60) T360_W(61) T360_W(62) T360_W(63)
+  n = n < 0 ? 0 : (n > 63 ? 63 : n);
+  // s_getpc yields the address of the s_add below; the table starts 12 bytes further
+  const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 8u * (uint32_t)n));
+#define T360_W(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch 1f\n\t"
+  asm volatile(
+      "s_getpc_b64 vcc\n\t"
+      "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+      "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+      "s_setpc_b64 vcc\n\t"
+      T360_W(0) T360_W(1) T360_W(2) T360_W(3) T360_W(4) T360_W(5) T360_W(6) T360_W(7)
+      T360_W(8) T360_W(9) T360_W(10) T360_W(11) T360_W(12) T360_W(13) T360_W(14) T360_W(15)
+      T360_W(16) T360_W(17) T360_W(18) T360_W(19) T360_W(20) T360_W(21) T360_W(22) T360_W(23)
+      T360_W(24) T360_W(25) T360_W(26) T360_W(27) T360_W(28) T360_W(29) T360_W(30) T360_W(31)
+      T360_W(32) T360_W(33) T360_W(34) T360_W(35) T360_W(36) T360_W(37) T360_W(38) T360_W(39)
+      T360_W(40) T360_W(41) T360_W(42) T360_W(43) T360_W(44) T360_W(45) T360_W(46) T360_W(47)
+      T360_W(48) T360_W(49) T360_W(50) T360_W(51) T360_W(52) T360_W(53) T360_W(54) T360_W(55)
+      T360_W(56) T360_W(57) T360_W(58) T360_W(59) T360_W(60) T360_W(61) T360_W(62) T360_W(63)
+      "1:"
+      :
+      : "s"(skip)
+      : "memory", "vcc", "scc");
 #undef T360_W
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
 }
 
-// One frame of one tile, global -> LDS by DMA: NJ x (64 lanes x 16 bytes).  Lane i of
-// instruction j lands at lds_dst + 1024*j + 16*i.  SGPR-base + 32-bit VGPR-offset addressing, so
-// per frame only the scalar base changes; M0 (the LDS destination) is written and stepped inside
-// the statement that uses it.  hipcc does not count these loads (cdna_hip_programming.md 5.7):
-// completion is ours to track with wait_vmcnt().
-template <int NJ>
-__device__ __forceinline__ void dma_frame(const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
-                                          const int (&off)[16]) {
-  static_assert(NJ >= 1 && NJ <= 16, "1..16 DMA instructions per frame");
-#define T360_DMA(j)                                                                                   \
-  if (NJ > j)                                                                                         \
-    asm volatile("global_load_lds_dwordx4 %0, %1\n\ts_add_u32 m0, m0, %2\n\ts_nop 0" ::"v"(off[j]), \
-                 "s"(frame_base), "s"(lds_step)                                                       \
-                 : "memory");
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
-  T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3) T360_DMA(4) T360_DMA(5) T360_DMA(6) T360_DMA(7)
-  T360_DMA(8) T360_DMA(9) T360_DMA(10) T360_DMA(11) T360_DMA(12) T360_DMA(13) T360_DMA(14) T360_DMA(15)
-#undef T360_DMA
-}
-
-// run-time NJ -> the unrolled statement above (wave-uniform switch, loader wave only)
+// One frame of one tile, global -> LDS by DMA: nj x (64 lanes x 16 bytes), nj wave-uniform in
+// 1..16.  SGPR-base + 32-bit VGPR-offset addressing, so per frame only the scalar base changes;
+// M0 (the LDS destination) is written and stepped next to the instruction that uses it.  hipcc
+// does not count these loads (cdna_hip_programming.md 5.7): completion is ours to track with
+// wait_vmcnt().
+// The 16 {load; step M0; nop} triples are 16 bytes each and laid out back to back; a computed jump
+// enters the chain at triple 16-nj (Duff's device), so no per-frame decision tree.  Triple k moves
+// PIECE 15-k: `off[k]` must hold the source offset of piece 15-k, M0 starts at the last piece's
+// destination and walks down.
 __device__ __forceinline__ void dma_frame_n(int nj, const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
                                             const int (&off)[16]) {
-  switch (nj) {
-#define T360_C(n) case n: dma_frame<n>(frame_base, lds_dst, lds_step, off); break;
-    T360_C(1) T360_C(2) T360_C(3) T360_C(4) T360_C(5) T360_C(6) T360_C(7) T360_C(8)
-    T360_C(9) T360_C(10) T360_C(11) T360_C(12) T360_C(13) T360_C(14) T360_C(15) T360_C(16)
-#undef T360_C
-    default: break;
-  }
+  const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(16 - nj)));
+  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * lds_step));
+#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %16\n\ts_sub_u32 m0, m0, %17\n\ts_nop 0\n\t"
+  asm volatile(
+      "s_mov_b32 m0, %18\n\t"
+      "s_getpc_b64 vcc\n\t"
+      "s_add_u32 vcc_lo, vcc_lo, %19\n\t"
+      "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+      "s_setpc_b64 vcc\n\t"
+      T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3) T360_DMA(4) T360_DMA(5) T360_DMA(6) T360_DMA(7)
+      T360_DMA(8) T360_DMA(9) T360_DMA(10) T360_DMA(11) T360_DMA(12) T360_DMA(13) T360_DMA(14) T360_DMA(15)
+      :
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]),
+        "v"(off[8]), "v"(off[9]), "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]),
+        "s"(frame_base), "s"(lds_step), "s"(m0_start), "s"(skip)
+      : "memory", "vcc", "scc");
+#undef T360_DMA
 }
 
 __device__ __forceinline__ void frame_barrier() {
@@ -290,10 +307,11 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
   // is fixed per tile.  Lanes past the end of the box re-read chunk 0 into the slot's padding:
   // every DMA instruction runs with all 64 lanes (no exec juggling in the issue path).
   const uint32_t inv = (65536u + (uint32_t)t.cpr - 1u) / (uint32_t)t.cpr;  // exact q / cpr for q < 1024
-  int goff[kMaxLoaderInstr];
+  int goff[kMaxLoaderInstr];  // goff[k] = source offset of this loader's piece 15-k (dma_frame_n's order)
 #pragma unroll
-  for (int j = 0; j < kMaxLoaderInstr; j++) {
-    goff[j] = 0;
+  for (int k = 0; k < kMaxLoaderInstr; k++) {
+    const int j = kMaxLoaderInstr - 1 - k;
+    goff[k] = 0;
     if (j < nj) {  // wave-uniform
       int q = lane + 64 * (which + j * nloaders);
       q = q < g.nch ? q : 0;
@@ -304,17 +322,18 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
         sx += pl.sw;
       else if (sx >= pl.sw)
         sx -= pl.sw;
-      goff[j] = sy * pl.sstride + sx;
+      goff[k] = sy * pl.sstride + sx;
     }
   }
   auto issue = [&](int f, int slot) {
-    dma_frame_n(nj, pl.src + (size_t)f * pl.src_frame_bytes,
+    if (nj > 0) dma_frame_n(nj, pl.src + (size_t)f * pl.src_frame_bytes,
                 lds_base + (uint32_t)(slot * g.slot_bytes + which * 1024), (uint32_t)(nloaders * 1024), goff);
   };
   const int nf = f1 - f0;
   const int K = g.K;
   if (which == 0) trace_mark(a, 1);
-  for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
+  if (!(a.debug & 256))
+    for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
   if (which == 0) trace_mark(a, 2);
   int fill = (K - 1) % K;
   unsigned long long acc_wait = 0, acc_bar = 0, acc_issue = 0;
@@ -345,12 +364,12 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
   if (which == 0 && !(a.debug & (32 | 16))) trace_mark(a, 6);
 }
 
-template <int NPX>
+template <int NPX, int GROUP>
 __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
                                                const uint8_t* __restrict__ lds, int f0, int f1) {
   const RingGeom g = ring_geom(t, a.ring_bytes);
   PixelSetup<NPX> px;
-  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px);
+  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px, a.debug);
   if (a.trace && !(a.debug & 16)) {
     pin_pixels<NPX>(px);  // make the compiler wait for the loads before the timestamp
     if (threadIdx.x < 64) trace_mark(a, 4);
@@ -366,7 +385,7 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
     unsigned long long c0 = tracing ? wall_clock64() : 0;
     frame_barrier();
     unsigned long long c1 = tracing ? wall_clock64() : 0;
-    if (!(a.debug & 8)) gather_store<NPX>(px, box, g.pitch, d, pl.dstride, dword_store);
+    if (!(a.debug & 8)) gather_store<NPX, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
     if (tracing) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       acc_bar += c1 - c0;
@@ -385,7 +404,137 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
   }
 }
 
-__global__ __launch_bounds__(512, 1) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
+// ---- variant without a loader wave: every consumer wave also moves a quarter of the box -------
+// Workgroup = 4 waves (one per SIMD, so any number of workgroups spreads evenly over the SIMDs;
+// the 5-wave loader/consumer workgroup leaves the 4th slot of a CU empty most of the time).
+// Wave w owns the 1 KiB pieces w, w+4, w+8, w+12 of every frame.  Per frame:
+//     wait until MY pieces of frame i have landed | BARRIER i | refill the slot frame i-1 used
+//     with my pieces of frame i+K-1 | gather frame i, store
+// The wave's vmcnt stream now also holds its output stores, which may complete out of order with
+// the loads.  The counted wait stays SAFE: loads complete in order among themselves, so
+// "at most D operations outstanding", D = my loads younger than frame i's, implies frame i's
+// pieces are done whatever the stores do; outstanding stores only make the wait conservative.
+__device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
+                                            const int (&off)[4]) {
+  const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(4 - nj)));
+  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * lds_step));
+#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %4\n\ts_sub_u32 m0, m0, %5\n\ts_nop 0\n\t"
+  asm volatile(
+      "s_mov_b32 m0, %6\n\t"
+      "s_getpc_b64 vcc\n\t"
+      "s_add_u32 vcc_lo, vcc_lo, %7\n\t"
+      "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+      "s_setpc_b64 vcc\n\t"
+      T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3)
+      :
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(frame_base), "s"(lds_step), "s"(m0_start), "s"(skip)
+      : "memory", "vcc", "scc");
+#undef T360_DMA
+}
+
+template <int NPX, int GROUP>
+__device__ __forceinline__ void self_loading_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
+                                                   const uint8_t* __restrict__ lds, int f0, int f1) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const RingGeom g = ring_geom(t, a.ring_bytes);
+  const int nj_all = (g.nch + 63) >> 6;
+  const int nj = (nj_all - wave + 3) >> 2;  // my pieces: wave, wave + 4, ... (0..4 of them)
+  const uint32_t inv = (65536u + (uint32_t)t.cpr - 1u) / (uint32_t)t.cpr;  // exact q / cpr for q < 1024
+  int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4 walks its chain backwards)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int j = 3 - k;
+    goff[k] = 0;
+    if (j < nj) {  // wave-uniform
+      int q = lane + 64 * (wave + 4 * j);
+      q = q < g.nch ? q : 0;  // lanes past the end of the box re-read chunk 0 into the slot's padding
+      const int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
+      const int sy = wrap_coord(t.y0 + r, pl.sh);
+      int sx = t.x0 + cc * kStageChunk;
+      if (sx < 0)
+        sx += pl.sw;
+      else if (sx >= pl.sw)
+        sx -= pl.sw;
+      goff[k] = sy * pl.sstride + sx;
+    }
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+  auto issue = [&](int f, int slot) {
+    if (nj > 0)
+      dma_frame_4(nj, pl.src + (size_t)f * pl.src_frame_bytes, lds_base + (uint32_t)(slot * g.slot_bytes + wave * 1024),
+                  4096u, goff);
+  };
+  const int nf = f1 - f0;
+  const int K = g.K;
+  if (!(a.debug & 256))
+    for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
+  if (lane == 0 && wave == 0) trace_mark(a, 2);
+
+  PixelSetup<NPX> px;
+  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px, a.debug);
+  pin_pixels<NPX>(px);  // hipcc's wait for its own loads lands here (and drains the prologue DMA with it)
+  if (lane == 0 && wave == 0) trace_mark(a, 4);
+
+  const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
+  uint8_t* __restrict__ d = pl.dst + (size_t)f0 * pl.dst_frame_bytes + out_pos<NPX>(pl, t, dword_store);
+  const uint8_t* __restrict__ box = lds;
+  const uint8_t* const ring_end = lds + K * g.slot_bytes;
+  int fill = (K - 1) % K;
+  for (int i = 0; i < nf; i++) {
+    // my loads younger than frame i's: frames i+1 .. min(i+K-2, nf-1), nj instructions each
+    if (nj > 0 && !(a.debug & 512)) wait_vmcnt((a.debug & 4) ? 0 : min(K - 2, nf - 1 - i) * nj);
+    if (!(a.debug & 1024)) frame_barrier();  // frame i is complete in LDS; everyone has left frame i-1's slot
+    if (i + K - 1 < nf && !(a.debug & 4)) issue(f0 + i + K - 1, fill);
+    fill = fill + 1 == K ? 0 : fill + 1;
+    if (!(a.debug & 8)) gather_store<NPX, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
+    d += pl.dst_frame_bytes;
+    box += g.slot_bytes;
+    if (box == ring_end) box = lds;
+    if (i == 0 && lane == 0 && wave == 0) trace_mark(a, 5);
+  }
+  if (lane == 0 && wave == 0) trace_mark(a, 7);
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void remap_tiled_cubic_self_kernel(TiledArgs a) {
+  constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
+  extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
+  int b = xcd_contiguous(blockIdx.x, a.total_tiles);
+  TiledPlane pl = a.plane[0];
+  if (a.nplanes > 1 && b >= pl.ntiles) {
+    b -= pl.ntiles;
+    pl = a.plane[1];
+    if (a.nplanes > 2 && b >= pl.ntiles) {
+      b -= pl.ntiles;
+      pl = a.plane[2];
+      if (a.nplanes > 3 && b >= pl.ntiles) {
+        b -= pl.ntiles;
+        pl = a.plane[3];
+      }
+    }
+  }
+  const TileDesc t = pl.tiles[b];
+  const int f0 = blockIdx.y * a.frames_per_block;
+  const int f1 = min(f0 + a.frames_per_block, a.nframes);
+  if (threadIdx.x == 0) trace_mark(a, 0);
+  if (a.trace && (a.debug & 32) && threadIdx.x == 0) {  // where did this workgroup run?
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
+  if (t.kind == kTileStaged16)
+    self_loading_waves<1, GROUP>(a, pl, t, lds, f0, f1);
+  else
+    self_loading_waves<4, GROUP>(a, pl, t, lds, f0, f1);
+}
+
+// VARIANT bit 0: LDS reads in groups of 2 pixels instead of 4 (fewer registers);
+//         bit 1: cap registers for 6 waves per SIMD (4 workgroups of 5 waves per CU)
+template <int VARIANT>
+__global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
+  constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
   int b = xcd_contiguous(blockIdx.x, a.total_tiles);
   // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
@@ -417,9 +566,9 @@ __global__ __launch_bounds__(512, 1) void remap_tiled_cubic_dma_kernel(TiledArgs
   if (wave >= kLoaderWave) {
     loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
   } else if (t.kind == kTileStaged16) {
-    consumer_waves<1>(a, pl, t, lds, f0, f1);
+    consumer_waves<1, GROUP>(a, pl, t, lds, f0, f1);
   } else {
-    consumer_waves<4>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
+    consumer_waves<4, GROUP>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
   }
 }
 
@@ -498,7 +647,7 @@ __device__ __forceinline__ void staged_tile_regs(const TiledArgs& a, const Tiled
   __syncthreads();
   for (int f = f0; f < f1; f++) {
     if (f + 1 < f1) fetch(f + 1);  // in flight while this frame is computed
-    gather_store<NPX>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, pl.dstride, dword_store);
+    gather_store<NPX, 4>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, pl.dstride, dword_store);
     __syncthreads();  // everyone is done reading this frame's box
     if (f + 1 < f1) {
       commit();
@@ -558,20 +707,49 @@ hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) {
-  if (a.total_tiles <= 0 || a.nframes <= 0) return hipSuccess;
-  const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
-  const int nload = a.loader_waves < 1 ? 1 : (a.loader_waves > 4 ? 4 : a.loader_waves);
+template <int VARIANT>
+static hipError_t launch_dma_variant(const TiledArgs& a, int groups, int nload, hipStream_t stream) {
   static int configured_lds = 0;
   if (a.ring_bytes > 64 * 1024 && configured_lds < a.ring_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_dma_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_dma_kernel<VARIANT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
     if (e != hipSuccess) return e;
     configured_lds = a.ring_bytes;
   }
-  hipLaunchKernelGGL(remap_tiled_cubic_dma_kernel, dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload), (size_t)a.ring_bytes,
-                     stream, a);
+  hipLaunchKernelGGL(remap_tiled_cubic_dma_kernel<VARIANT>, dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload),
+                     (size_t)a.ring_bytes, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) {
+  if (a.total_tiles <= 0 || a.nframes <= 0) return hipSuccess;
+  const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
+  const int nload = a.loader_waves < 1 ? 1 : (a.loader_waves > 4 ? 4 : a.loader_waves);
+  if (a.variant & 4) {
+    static int configured_self = 0;
+    if (a.ring_bytes > 64 * 1024 && configured_self < a.ring_bytes) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_self_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_self_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
+      if (e != hipSuccess) return e;
+      configured_self = a.ring_bytes;
+    }
+    if (a.variant & 1)
+      hipLaunchKernelGGL(remap_tiled_cubic_self_kernel<1>, dim3(a.total_tiles, groups, 1), dim3(256), (size_t)a.ring_bytes,
+                         stream, a);
+    else
+      hipLaunchKernelGGL(remap_tiled_cubic_self_kernel<0>, dim3(a.total_tiles, groups, 1), dim3(256), (size_t)a.ring_bytes,
+                         stream, a);
+    return hipGetLastError();
+  }
+  switch (a.variant & 3) {
+    case 0: return launch_dma_variant<0>(a, groups, nload, stream);
+    case 1: return launch_dma_variant<1>(a, groups, nload, stream);
+    case 2: return launch_dma_variant<2>(a, groups, nload, stream);
+    default: return launch_dma_variant<3>(a, groups, nload, stream);
+  }
 }
 
 hipError_t launch_remap_tiled_cubic_regs(const TiledArgs& a, hipStream_t stream) {

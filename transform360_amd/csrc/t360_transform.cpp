@@ -186,6 +186,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
   }
   if (getenv("T360_NO_DMA")) use_dma_ = false;
+  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 7;
   if (const char* e = getenv("T360_LOADERS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) loader_waves_ = v;
@@ -564,6 +565,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
   fused.ring_bytes = ring_bytes_;
   fused.loader_waves = loader_waves_;
+  fused.variant = dma_variant_;
   fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
   const bool multi = n_frames > 1;
   TiledArgs direct = fused;  // the pole tiles too large to stage, all planes in one small launch
@@ -580,7 +582,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       TiledPlane tp;
       memset(&tp, 0, sizeof(tp));
       tp.src = s.ptr;
-      tp.src_frame_bytes = s.frame_bytes;
+      tp.src_frame_bytes = (fused.debug & 64) ? 0 : s.frame_bytes;  // bit6: every frame reads frame 0 (cache-resident input)
       tp.dst = j.out;
       tp.dst_frame_bytes = j.out_frame_bytes;
       tp.sw = j.in_w;

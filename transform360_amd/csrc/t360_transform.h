@@ -107,10 +107,11 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  int ring_bytes_ = 48 * 1024;  // LDS ring of the DMA-staged gather: 3 workgroups per CU are resident
+  int ring_bytes_ = 36 * 1024;  // LDS ring of the DMA-staged gather: 4 workgroups (78 VGPRs, 5 waves each) per CU
                                 // (VGPR-limited, measured), 3 x 48 KiB fits the 160 KiB LDS
   bool use_dma_ = true;
   int loader_waves_ = 1;
+  int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit1 register cap, bit2 no loader wave
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
