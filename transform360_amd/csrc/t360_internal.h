@@ -59,6 +59,7 @@ struct SegmentDev {
   int kx_off, kx_len;  // into the packed tap arrays (int32 taps and float taps share offsets)
   int ky_off, ky_len;
   int fixed_point;     // 1: Q8 x Q8 integer path, 0: float path
+  int kxp_off, kx_groups;  // packed byte taps of the fast low-pass path (kx_groups = 0: not eligible)
 };
 
 // One unit of low-pass work: a tile of one segment (tiles never straddle segments because the

@@ -90,6 +90,13 @@ struct LowpassArgs {
   const float* taps_f32;      // packed float taps, same offsets
   int max_rows;               // max over tiles of (tile.h + 2*ry): sizes the LDS row buffer
   int tile_w;                 // tile width used when the list was built
+  // fast Q8 path (lowpass_q8_kernel): tiles of <= 128 x 128 px inside one qualifying segment
+  const LowpassTile* fast_tiles;
+  int nfast;
+  int fast_ky;                // vertical taps of every fast tile (3, 5 or 7)
+  int fast_lds_bytes;         // max over fast tiles of the staged source rectangle
+  const uint32_t* taps_pk;    // horizontal Q8 taps packed 4 per dword, zero padded (SegmentDev::kxp_off)
+  int dst_dword_ok;           // dst base and stride are multiples of 4
 };
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
 

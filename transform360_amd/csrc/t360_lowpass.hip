@@ -13,9 +13,12 @@
 //       symmetric vertical kernel (ascending otherwise), out = sat_u8(rint(c))
 //
 // One workgroup per (frame, tile); a tile is a <= tile_w x tile_h rectangle inside ONE segment.
-// Pass 1 writes the row-filtered values of the tile's rows plus the vertical halo to LDS,
-// pass 2 reads them column-wise.  Source bytes come straight from global memory (L2-resident:
-// neighbouring tiles overlap by the kernel radius).
+// Two kernels:
+//   lowpass_q8_kernel   the fast path (fixed-point segments, byte-sized horizontal taps, 3/5/7 vertical
+//                       taps): registers only, v_dot4 row pass, see below;
+//   lowpass_kernel      everything else (float path, long kernels, odd alignments): pass 1 writes the
+//                       row-filtered values of the tile's rows plus the vertical halo to LDS, pass 2 reads
+//                       them column-wise; source bytes come straight from global memory.
 #include <hip/hip_runtime.h>
 
 #include "t360_internal.h"
@@ -96,10 +99,200 @@ __global__ __launch_bounds__(256) void lowpass_kernel(LowpassArgs a) {
   }
 }
 
+
+// ============================ fast path: Q8 x Q8 fixed point ===================================
+// For segments on the fixed-point path whose horizontal taps all fit a byte (every Gaussian of
+// >= 3 taps does, <= 64 taps) and whose vertical kernel has KY in {3, 5, 7} taps; plane width,
+// bases and strides multiples of 4.  One workgroup per tile of <= 128 x 128 px of ONE segment:
+//   1. the tile's source rectangle (+ kernel radius) goes to LDS as bytes, ONE coalesced dword
+//      load per source dword (the first version let every lane load its own window from global
+//      memory: 6x redundant, and the vector-memory path, not HBM, bound the kernel).  The
+//      replicate border is resolved here: the plane is a whole number of dwords wide, so a dword
+//      is either inside the row or entirely outside it (splat of the row's first / last byte);
+//      rows above / below the plane are clamped.
+//   2. a row group of 16 or 32 lanes owns <= 64 / 128 consecutive pixels of a run of rows, 4 px
+//      per lane.  Per source row and per 16 taps a lane reads the <= 6 LDS dwords covering its 4
+//      pixels' windows, realigns them (v_alignbit) and takes the row pass as v_dot4_u32_u8 against
+//      the packed taps held in SGPRs: 2 VALU per 4 taps per pixel.
+//   3. the last KY row-pass results stay in registers (sliding window); the column pass is KY
+//      v_mad_u32_u24 per pixel; 4 pixels leave as one dword store.
+// Arithmetic is identical to the generic kernel above: r = SUM kx_q8*src, c = SUM ky_q8*r,
+// out = sat_u8((c + 32768) >> 16), all exact in int32 (r < 2^17, taps <= 256: 24-bit multiplies).
+
+// NG = tap groups (dwords of 4 packed taps) the instantiation holds; EXACT: G == NG, no guards.
+template <int KY, int NG, bool EXACT>
+__device__ __forceinline__ void lowpass_q8_rows(const LowpassArgs& a, const LowpassTile& t,
+                                                const uint32_t* __restrict__ box, int pitch, int m, int nd, int G,
+                                                const uint32_t* __restrict__ kxp, const uint32_t (&kyv)[KY],
+                                                uint8_t* __restrict__ dst) {
+  constexpr int ry = KY >> 1;
+  uint32_t kx4[NG];
+#pragma unroll
+  for (int j = 0; j < NG; j++) kx4[j] = (EXACT || j < G) ? kxp[j] : 0u;  // scalar loads, once
+
+  // lanes per row group: 16 for tiles up to 64 px wide, else 32
+  const int lshift = t.w <= 64 ? 4 : 5;
+  const int lir = threadIdx.x & ((1 << lshift) - 1), grp = threadIdx.x >> lshift;
+  const int ngroups = 256 >> lshift;
+  const int rpg = (t.h + ngroups - 1) / ngroups;
+  const int r0 = grp * rpg;  // first output row of this group, relative to the tile
+  const int r1 = min(r0 + rpg, t.h);
+  if (r0 >= r1 || 4 * lir >= t.w) return;
+  const int px0 = t.x0 + 4 * lir;
+  const int npx = min(4, t.w - 4 * lir);
+  const bool dword_out = npx == 4 && a.dst_dword_ok && (px0 & 3) == 0;
+  const uint32_t mshift = (uint32_t)m * 8u;
+
+  // the last KY row-pass results: slot (row index mod KY); the row loop is unrolled KY times so
+  // slot numbers are compile-time constants and the window never moves between registers
+  uint32_t win[KY][4];
+#pragma unroll
+  for (int k = 0; k < KY; k++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) win[k][p] = 0u;
+
+  const uint32_t* __restrict__ lane_row = box + r0 * pitch + lir;
+  uint8_t* __restrict__ d = dst + (size_t)(t.y0 + r0) * a.dstride + px0;
+  const int rend = r1 + 2 * ry;  // staged rows r0 .. rend-1 (staged row r = source row t.y0 - ry + r)
+  for (int rb = r0; rb < rend; rb += KY) {
+#pragma unroll
+    for (int u = 0; u < KY; u++) {
+      const int r = rb + u;
+      if (r < rend) {
+        uint32_t D[NG + 2];
+#pragma unroll
+        for (int i = 0; i < NG + 2; i++) D[i] = (i < NG + 1 || m != 0) && (EXACT || i < nd) ? lane_row[i] : 0u;
+        uint32_t R[NG + 1];  // R[i] = source bytes (px0 - rx) + 4i .. +3
+#pragma unroll
+        for (int i = 0; i < NG + 1; i++) R[i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], mshift);
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+          if (EXACT || j < G) {  // wave-uniform
+            acc[0] = __builtin_amdgcn_udot4(R[j], kx4[j], acc[0], false);
+            acc[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(R[j + 1], R[j], 8u), kx4[j], acc[1], false);
+            acc[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(R[j + 1], R[j], 16u), kx4[j], acc[2], false);
+            acc[3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(R[j + 1], R[j], 24u), kx4[j], acc[3], false);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) win[u][p] = acc[p];
+        if (r >= r0 + 2 * ry) {  // the window of output row r - 2 ry is complete: slots u+1 .. u (mod KY)
+          uint32_t c[4];
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            c[p] = 1u << 15;
+#pragma unroll
+            for (int k = 0; k < KY; k++) c[p] = __umul24(kyv[k], win[(u + 1 + k) % KY][p]) + c[p];
+            c[p] = min(c[p], 0x00ffffffu);  // byte 2 is now sat_u8(c >> 16)
+          }
+          if (dword_out) {
+            const uint32_t lo = __builtin_amdgcn_perm(c[1], c[0], 0x0c0c0602u);  // [c0.b2, c1.b2, 0, 0]
+            const uint32_t hi = __builtin_amdgcn_perm(c[3], c[2], 0x06020c0cu);  // [0, 0, c2.b2, c3.b2]
+            *reinterpret_cast<uint32_t*>(d) = lo | hi;
+          } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+              if (p < npx) d[p] = (uint8_t)(c[p] >> 16);
+          }
+          d += a.dstride;
+        }
+        lane_row += pitch;
+      }
+    }
+  }
+}
+
+template <int KY>
+__global__ __launch_bounds__(256) void lowpass_q8_kernel(LowpassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_rows[];
+  uint32_t* __restrict__ box = reinterpret_cast<uint32_t*>(lds_rows);
+
+  const LowpassTile t = a.fast_tiles[blockIdx.x];
+  const SegmentDev s = a.segs[t.seg];
+  const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.y * a.src_frame_bytes;
+  uint8_t* __restrict__ dst = a.dst + (size_t)blockIdx.y * a.dst_frame_bytes;
+  const int rx = s.kx_len >> 1;
+  constexpr int ry = KY >> 1;
+  const int G = s.kx_groups;  // packed tap dwords, 1..16
+  const uint32_t* __restrict__ kxp = a.taps_pk + s.kxp_off;
+  const int* __restrict__ ky = a.taps_q8 + s.ky_off;
+  uint32_t kyv[KY];
+#pragma unroll
+  for (int k = 0; k < KY; k++) kyv[k] = (uint32_t)ky[k];
+
+  // ---- 1. stage the source rectangle ----
+  const int m = (t.x0 - rx) & 3;            // byte offset of the first needed byte inside its dword
+  const int dx0 = (t.x0 - rx - m) >> 2;     // first staged dword column (may be < 0)
+  const int nd = G + 1 + (m ? 1 : 0);       // dwords one lane's window spans
+  const int ndw = ((t.w + 3) >> 2) + nd - 1;  // staged dwords per row (<= 32 + 17)
+  const int pitch = (ndw + 3) & ~3;           // LDS row pitch in dwords: rows start 16-byte aligned
+  const int rows = t.h + 2 * ry;
+  const int W4 = a.w >> 2;
+  {
+    // 16 lanes x 16 bytes per row, 16 rows per pass of the workgroup
+    const int c4 = (threadIdx.x & 15) * 4;
+    if (c4 < ndw) {
+      const int di = dx0 + c4;
+      const bool inside = di >= 0 && di + 4 <= W4;
+      for (int r = threadIdx.x >> 4; r < rows; r += 16) {
+        const uint32_t* __restrict__ q =
+            reinterpret_cast<const uint32_t*>(src + (size_t)clampi(t.y0 - ry + r, 0, a.h - 1) * a.sstride);
+        uint4 v;
+        if (inside) {
+          v = *reinterpret_cast<const uint4*>(q + di);  // dword aligned; the hardware takes it
+        } else {
+          uint32_t e[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int dk = di + k;
+            uint32_t u = q[clampi(dk, 0, W4 - 1)];
+            if (dk < 0) u = (u & 0xffu) * 0x01010101u;
+            if (dk >= W4) u = (u >> 24) * 0x01010101u;
+            e[k] = u;
+          }
+          v = make_uint4(e[0], e[1], e[2], e[3]);
+        }
+        *reinterpret_cast<uint4*>(box + r * pitch + c4) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2./3. row pass from LDS, column pass in registers ----
+  // specialised on the number of tap groups so the packed taps are loop-invariant scalars
+  switch (G) {
+    case 1: lowpass_q8_rows<KY, 1, true>(a, t, box, pitch, m, nd, G, kxp, kyv, dst); break;
+    case 2: lowpass_q8_rows<KY, 2, true>(a, t, box, pitch, m, nd, G, kxp, kyv, dst); break;
+    case 3: lowpass_q8_rows<KY, 3, true>(a, t, box, pitch, m, nd, G, kxp, kyv, dst); break;
+    case 4: lowpass_q8_rows<KY, 4, true>(a, t, box, pitch, m, nd, G, kxp, kyv, dst); break;
+    default:
+      if (G <= 8)
+        lowpass_q8_rows<KY, 8, false>(a, t, box, pitch, m, nd, G, kxp, kyv, dst);
+      else if (G <= 12)
+        lowpass_q8_rows<KY, 12, false>(a, t, box, pitch, m, nd, G, kxp, kyv, dst);
+      else
+        lowpass_q8_rows<KY, 16, false>(a, t, box, pitch, m, nd, G, kxp, kyv, dst);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream) {
-  if (a.ntiles <= 0 || nframes <= 0) return hipSuccess;
+  if (nframes <= 0) return hipSuccess;
+  if (a.nfast > 0) {
+    const dim3 grid(a.nfast, nframes, 1);
+    switch (a.fast_ky) {
+      // LDS: (128 + 2*ry) rows of up to 32 + 17 dwords
+      case 3: hipLaunchKernelGGL(lowpass_q8_kernel<3>, grid, dim3(256), (size_t)a.fast_lds_bytes, stream, a); break;
+      case 5: hipLaunchKernelGGL(lowpass_q8_kernel<5>, grid, dim3(256), (size_t)a.fast_lds_bytes, stream, a); break;
+      case 7: hipLaunchKernelGGL(lowpass_q8_kernel<7>, grid, dim3(256), (size_t)a.fast_lds_bytes, stream, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (a.ntiles <= 0) return hipSuccess;
   const size_t lds = (size_t)a.max_rows * (size_t)a.tile_w * sizeof(int);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 64 * 1024) {

@@ -379,8 +379,31 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     std::vector<SegmentDev> segs;
     std::vector<int> q8;
     std::vector<float> f32;
+    std::vector<uint32_t> pk;
+    p.seg_fast.clear();
+    p.fast_ky = 0;
     for (const Segment& s : p.filter.segments) {
       SegmentDev d;
+      // register-only Q8 kernel (t360_lowpass.hip): fixed-point segment, horizontal taps that fit
+      // a byte (<= 64 of them), 3/5/7 vertical taps shared by all eligible segments of the plane
+      bool fast = s.fixed_point && s.kx_q8.size() <= 64 && (s.ky_q8.size() == 3 || s.ky_q8.size() == 5 || s.ky_q8.size() == 7) &&
+                  (p.fast_ky == 0 || p.fast_ky == (int)s.ky_q8.size()) && !getenv("T360_NO_FAST_LOWPASS");
+      for (int v : s.kx_q8) fast = fast && v >= 0 && v <= 255;
+      d.kxp_off = (int)pk.size();
+      d.kx_groups = 0;
+      if (fast) {
+        p.fast_ky = (int)s.ky_q8.size();
+        d.kx_groups = ((int)s.kx_q8.size() + 3) / 4;
+        for (int g = 0; g < d.kx_groups; g++) {
+          uint32_t w = 0;
+          for (int b = 0; b < 4; b++) {
+            const size_t k = (size_t)g * 4 + b;
+            if (k < s.kx_q8.size()) w |= (uint32_t)s.kx_q8[k] << (8 * b);
+          }
+          pk.push_back(w);
+        }
+      }
+      p.seg_fast.push_back(fast ? 1 : 0);
       d.left = s.left;
       d.top = s.top;
       d.width = s.width;
@@ -397,9 +420,13 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
       segs.push_back(d);
     }
     if (!segs.empty()) {
+      if (pk.empty()) pk.push_back(0);
       if (!p.segs.reserve(segs.size() * sizeof(SegmentDev)) || !p.taps_q8.reserve(q8.size() * sizeof(int)) ||
-          !p.taps_f32.reserve(f32.size() * sizeof(float)))
+          !p.taps_f32.reserve(f32.size() * sizeof(float)) || !p.taps_pk.reserve(pk.size() * sizeof(uint32_t)))
         return check(hipErrorOutOfMemory, "hipMalloc(segments)");
+      if (!check(hipMemcpyAsync(p.taps_pk.as<void>(), pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                stream_), "hipMemcpy(taps)"))
+        return false;
       if (!check(hipMemcpyAsync(p.segs.as<void>(), segs.data(), segs.size() * sizeof(SegmentDev),
                                 hipMemcpyHostToDevice, stream_), "hipMemcpy(segments)") ||
           !check(hipMemcpyAsync(p.taps_q8.as<void>(), q8.data(), q8.size() * sizeof(int),
@@ -415,11 +442,18 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   return true;
 }
 
+// b directly continues a to the right with the same band and bit-identical kernels
+static bool same_run(const t360::Segment& a, const t360::Segment& b) {
+  return a.top == b.top && a.height == b.height && a.left + a.width == b.left && a.fixed_point == b.fixed_point &&
+         a.kx_q8 == b.kx_q8 && a.ky_q8 == b.ky_q8;
+}
+
 // Tile work list of the low-pass for a plane of w x h (reference filterPlane's segment loop,
 // VideoFrameTransform.cpp:630-691: every segment once per eye).
 bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex) {
   if (p.tiles_w == w && p.tiles_h == h) return true;
-  std::vector<LowpassTile> tiles;
+  std::vector<LowpassTile> tiles, fast_tiles, rest_tiles;
+  int max_rows_rest = 0, fast_lds = 0;
   int ox[2] = {0, 0}, oy[2] = {0, 0}, eyes = 1;
   if (ctx_.input_stereo_format == STEREO_FORMAT_LR) {
     eyes = 2;
@@ -459,7 +493,39 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
           t.h = std::min(th, s.height - y);
           tiles.push_back(t);
           max_rows = std::max(max_rows, t.h + 2 * ry);
+          if (!p.seg_fast[i]) {
+            rest_tiles.push_back(t);
+            max_rows_rest = std::max(max_rows_rest, t.h + 2 * ry);
+          }
         }
+      if (p.seg_fast[i]) {
+        // Horizontally adjacent segments of a band with IDENTICAL kernels are filtered as one run:
+        // sepFilter2D on an ROI reads the parent's real pixels beyond the ROI, so with equal kernels
+        // the result does not depend on where the ROI borders are.  Runs are cut into tiles of
+        // <= 128 x 128 px: 8 row groups of 32 lanes x 4 px per workgroup.
+        const size_t n = p.filter.segments.size();
+        const bool continues_prev = i > 0 && p.seg_fast[i - 1] && same_run(p.filter.segments[i - 1], s);
+        if (!continues_prev) {
+          int run_w = s.width;
+          for (size_t k = i + 1; k < n && p.seg_fast[k] && same_run(p.filter.segments[k - 1], p.filter.segments[k]); k++)
+            run_w += p.filter.segments[k].width;
+          bool inside = L + run_w <= w;  // every member was range-checked above only one at a time
+          if (!inside) run_w = s.width;
+          for (int y = 0; y < s.height; y += 128)
+            for (int x = 0; x < run_w; x += 128) {
+              LowpassTile t;
+              t.seg = (int)i;
+              t.x0 = L + x;
+              t.y0 = T + y;
+              t.w = std::min(128, run_w - x);
+              t.h = std::min(128, s.height - y);
+              fast_tiles.push_back(t);
+              // staged rectangle: (h + 2 ry) rows of ceil(w/4) + groups + 1 dwords, 16-byte row pitch
+              const int ndw = (t.w + 3) / 4 + ((int)s.kx_q8.size() + 3) / 4 + 1;
+              fast_lds = std::max(fast_lds, (t.h + 2 * ry) * ((ndw + 3) & ~3) * 4);
+            }
+        }
+      }
     }
   p.ntiles = (int)tiles.size();
   p.max_rows = max_rows;
@@ -471,6 +537,23 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
         !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
       return false;
   }
+  p.nfast = (int)fast_tiles.size();
+  p.nrest = (int)rest_tiles.size();
+  p.max_rows_rest = max_rows_rest;
+  p.fast_lds_bytes = fast_lds;
+  if (p.nfast) {
+    if (!p.tiles_fast.reserve(fast_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(p.tiles_fast.as<void>(), fast_tiles.data(), fast_tiles.size() * sizeof(LowpassTile),
+                              hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
+      return false;
+  }
+  if (p.nrest) {
+    if (!p.tiles_rest.reserve(rest_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(p.tiles_rest.as<void>(), rest_tiles.data(), rest_tiles.size() * sizeof(LowpassTile),
+                              hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
+      return false;
+  }
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
   p.tiles_w = w;
   p.tiles_h = h;
   return true;
@@ -496,13 +579,30 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
   a.dstride = out_stride;
   a.w = w;
   a.h = h;
-  a.tiles = p.tiles.as<LowpassTile>();
-  a.ntiles = p.ntiles;
   a.segs = p.segs.as<SegmentDev>();
   a.taps_q8 = p.taps_q8.as<int>();
   a.taps_f32 = p.taps_f32.as<float>();
-  a.max_rows = p.max_rows;
+  a.taps_pk = p.taps_pk.as<uint32_t>();
   a.tile_w = kTileW;
+  a.dst_dword_ok = ((uintptr_t)d_out % 4 == 0 && out_stride % 4 == 0 && out_frame_bytes % 4 == 0) ? 1 : 0;
+  const bool src_dword_ok = (uintptr_t)d_in % 4 == 0 && in_stride % 4 == 0 && in_frame_bytes % 4 == 0 && w % 4 == 0 && w >= 4;
+  if (p.nfast > 0 && src_dword_ok) {
+    a.fast_tiles = p.tiles_fast.as<LowpassTile>();
+    a.nfast = p.nfast;
+    a.fast_ky = p.fast_ky;
+    a.fast_lds_bytes = p.fast_lds_bytes;
+    a.tiles = p.tiles_rest.as<LowpassTile>();
+    a.ntiles = p.nrest;
+    a.max_rows = p.max_rows_rest;
+  } else {
+    a.fast_tiles = nullptr;
+    a.nfast = 0;
+    a.fast_ky = 0;
+    a.fast_lds_bytes = 0;
+    a.tiles = p.tiles.as<LowpassTile>();
+    a.ntiles = p.ntiles;
+    a.max_rows = p.max_rows;
+  }
   return check(launch_lowpass(a, n_frames, stream_), "low-pass launch");
 }
 

@@ -69,9 +69,14 @@ class VideoFrameTransform {
     t360::DeviceBuffer lut;                        // LutEntry[map_h][map_w]
     // low-pass
     t360::FilterConfig filter;
-    t360::DeviceBuffer segs, taps_q8, taps_f32, tiles;
-    int tiles_w = -1, tiles_h = -1;  // plane size the tile list was built for
-    int ntiles = 0, max_rows = 0;
+    t360::DeviceBuffer segs, taps_q8, taps_f32, taps_pk, tiles;
+    std::vector<int> seg_fast;       // per segment: eligible for the register-only Q8 kernel
+    int fast_ky = 0;                 // vertical taps shared by the eligible segments (3, 5, 7; 0 = none)
+    int tiles_w = -1, tiles_h = -1;  // plane size the tile lists were built for
+    int ntiles = 0, max_rows = 0;    // generic tiles covering EVERY segment (any alignment)
+    // when the buffers are dword friendly: fast tiles of the eligible segments + generic tiles of the rest
+    t360::DeviceBuffer tiles_fast, tiles_rest;
+    int nfast = 0, nrest = 0, max_rows_rest = 0, fast_lds_bytes = 0;
     bool full_cover = false;
     // LDS-tiled gather
     t360::GatherPlan plan;
