@@ -40,8 +40,8 @@ MAP_CASES = {
     "odd_sizes": (dict(enable_low_pass_filter=0, interpolation_alg=LINEAR), (1001, 499, 336, 224)),
 }
 
-# layouts the oracle restates but the HIP path does not generate yet
-ORACLE_ONLY_MAP_CASES = {
+# the remaining output layouts: per-column / per-row libm tables on the HIP path
+LAYOUT_MAP_CASES = {
     "eac32": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_EAC_32), (1024, 512, 384, 256)),
     "equirect_out": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_EQUIRECT, fixed_yaw=77), (1024, 512, 512, 256)),
     "barrel": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_BARREL), (1024, 512, 640, 256)),
@@ -86,7 +86,7 @@ FRAME_CASES = {
     "tiny": (dict(enable_low_pass_filter=0), (64, 32, 48, 32), 3, 5),
 }
 
-ORACLE_ONLY_FRAME_CASES = {
+LAYOUT_FRAME_CASES = {
     "barrel_cubic": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_BARREL), (1024, 512, 640, 256), 0, 0),
     "barrel_split_linear": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_BARREL_SPLIT, interpolation_alg=LINEAR),
                             (1024, 512, 384, 256), 0, 0),

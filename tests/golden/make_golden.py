@@ -81,7 +81,7 @@ def main():
     assert O.ref_available(), "oracle/_ref could not be built: is /root/reference mounted?"
 
     maps = {}
-    for name, (ov, dims) in {**cases.MAP_CASES, **cases.ORACLE_ONLY_MAP_CASES}.items():
+    for name, (ov, dims) in {**cases.MAP_CASES, **cases.LAYOUT_MAP_CASES}.items():
         r = O.Ref(cases.make_ctx(ov))
         assert r.generateMapForPlane(*dims, 0)
         rec = map_record(r.map(0))
@@ -99,7 +99,7 @@ def main():
         r.close()
 
     frames = {}
-    for name, (ov, dims, pin, pout) in {**cases.FRAME_CASES, **cases.ORACLE_ONLY_FRAME_CASES}.items():
+    for name, (ov, dims, pin, pout) in {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES}.items():
         in_w, in_h, out_w, out_h = dims
         r = O.Ref(cases.make_ctx(ov))
         assert r.generateMapForPlane(*dims, 0)

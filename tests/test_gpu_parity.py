@@ -41,10 +41,14 @@ def padded_cuda(h, w, pad, fill):
 
 
 # ---------------------------------------------------------------- projection kernel
-@pytest.mark.parametrize("name", sorted(cases.MAP_CASES))
+ALL_MAPS = {**cases.MAP_CASES, **cases.LAYOUT_MAP_CASES}
+ALL_FRAMES = {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES}
+
+
+@pytest.mark.parametrize("name", sorted(ALL_MAPS))
 def test_map_bit_exact(name, T, oracle_mod, golden):
     O = oracle_mod
-    ov, dims = cases.MAP_CASES[name]
+    ov, dims = ALL_MAPS[name]
     ctx = cases.make_ctx(ov)
     with T.VideoFrameTransform(ctx) as t:
         assert t.generateMapForPlane(*dims, 0)
@@ -63,13 +67,17 @@ def test_map_bit_exact(name, T, oracle_mod, golden):
                     "gpu %s ref %s" % (name, len(bad), m.size, r, c, k, float(m[r, c, k]).hex(), float(ref[r, c, k]).hex()))
 
 
-def test_unsupported_layout_is_refused_not_faked(T):
-    from transform360_amd.abi import LAYOUT_EAC_32
-    with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_EAC_32)) as t:
-        assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
+def test_unsupported_request_is_refused_not_faked(T):
+    # supersampled maps are not on the HIP path yet: the call must fail, not fall
+    # back to anything else
+    with T.VideoFrameTransform(filter_defaults(width_scale_factor=2.0, height_scale_factor=2.0)) as t:
+        ok = t.generateMapForPlane(1024, 512, 384, 256, 0)
         src = dev(np.zeros((512, 1024), np.uint8))
         dst = dev(np.zeros((256, 384), np.uint8))
-        assert not t.transformFramePlane(src, dst, 0)
+        assert not (ok and t.transformFramePlane(src, dst, 0))
+    from transform360_amd.abi import LAYOUT_N
+    with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_N)) as t:
+        assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
 
 
 # ---------------------------------------------------------------- low-pass configuration
@@ -89,17 +97,19 @@ def test_lowpass_config_matches(name, T, oracle_mod, golden):
 
 
 # ---------------------------------------------------------------- whole plane, device pointers
-@pytest.mark.parametrize("name", sorted(cases.FRAME_CASES))
+@pytest.mark.parametrize("name", sorted(ALL_FRAMES))
 def test_frame_case_device_pointers(name, T, oracle_mod, golden):
     O = oracle_mod
-    ov, dims, pin, pout = cases.FRAME_CASES[name]
+    ov, dims, pin, pout = ALL_FRAMES[name]
     in_w, in_h, out_w, out_h = dims
     ctx = cases.make_ctx(ov)
     src = cases.case_input(name, in_w, in_h, pin)
     # oracle
     o = O.Oracle(ctx, threads=4)
     assert o.generateMapForPlane(*dims, 0)
-    want = np.zeros((out_h, out_w), np.uint8)
+    # BARREL outputs are remapped with BORDER_TRANSPARENT: pixels without a mapping keep what the
+    # destination held, so every side starts from the same 0xA5 fill (as the golden vectors did)
+    want = np.full((out_h, out_w), 0xA5, np.uint8)
     assert o.transformFramePlane(src, want, 0)
     assert hx(O.fnv1a64(want)) == golden["frames"][name]["out"]
     # HIP path through the reference ABI with device pointers and the same padded strides

@@ -51,6 +51,14 @@ struct MapGenParams {
   float rot[9];      // float rotation coefficients in the reference's evaluation order (:1240-1244)
   float hfov, vfov, yaw_deg, pitch_deg;  // FLAT_FIXED
   float input_pixel_width;               // VideoFrameTransform.cpp:528-531
+  // EQUIRECT / BARREL / BARREL_SPLIT / EAC_32 outputs: the libm values the reference takes per
+  // pixel (sinf/cosf of yaw and pitch, tan of the face coordinate) depend on the column OR the row
+  // only; the host evaluates them with the same libm and the kernel looks them up.
+  //   EQUIRECT, BARREL : col_tab[2j] = sinf(yaw_j), [2j+1] = cosf(yaw_j); row_tab likewise for pitch
+  //   BARREL_SPLIT     : col_tab[2(vFace*map_w + j)], vFace in {0,1}; row_tab as above
+  //   EAC_32           : col_tab[j] = warped face x, row_tab[i] = warped face y
+  const float* col_tab;
+  const float* row_tab;
 };
 
 // One low-pass segment (SegmentFilteringConfig + its kernels, VideoFrameTransform.h:25-38,150-159)

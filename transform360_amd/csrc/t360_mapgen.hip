@@ -10,10 +10,11 @@
 // atan2f/asinf.  Pixel-independent transcendental values (rotation sines/cosines) arrive
 // precomputed from the host in MapGenParams.
 //
-// Layouts handled on the GPU in this round: outputs CUBEMAP_32, CUBEMAP_23_OFFCENTER,
-// FLAT_FIXED; inputs EQUIRECT and CUBEMAP_32; all stereo packings; rotation and off-centre
-// projection.  EQUIRECT / BARREL / BARREL_SPLIT / EAC_32 outputs need per-pixel sinf/cosf/tan
-// and are rejected by the host side for now.
+// All output layouts of the public header: CUBEMAP_32, CUBEMAP_23_OFFCENTER, FLAT_FIXED, EQUIRECT,
+// BARREL, BARREL_SPLIT, EAC_32; inputs EQUIRECT and CUBEMAP_32; all stereo packings; rotation and
+// off-centre projection.  The sinf/cosf/tan values of the EQUIRECT / BARREL* / EAC_32 outputs
+// depend on the pixel's column or row only and come from host-evaluated tables
+// (MapGenParams::col_tab / row_tab), so they are the host libm's values by construction.
 #include <hip/hip_runtime.h>
 
 #include "t360_internal.h"
@@ -180,41 +181,112 @@ __global__ __launch_bounds__(256) void mapgen_kernel(MapGenParams P, float2* __r
   }
 
   float outX, outY;
+  bool hasMapping = true;
   if (P.output_layout == LAYOUT_FLAT_FIXED) {  // :1265-1271 (y is NOT flipped, :936)
     outX = div_rn((x - 0.5f) * P.hfov + P.yaw_deg, 360.0f) + 0.5f;
     outY = div_rn((y - 0.5f) * P.vfov - P.pitch_deg, 180.0f) + 0.5f;
     normalize_equirect(outX, outY, &outX, &outY);
   } else {
     y = 1.0f - y;  // :936-938
-    int face, vFace, hFace;
-    const unsigned char(*ftab)[3];
-    if (P.output_layout == LAYOUT_CUBEMAP_32) {  // :943-950
-      vFace = (int)(y * 2.0f);
-      hFace = (int)(x * 3.0f);
-      x = x * 3.0f - (float)hFace;
-      y = y * 2.0f - (float)vFace;
-      face = hFace + (1 - vFace) * 3;
-      ftab = kFace32;
-    } else {  // LAYOUT_CUBEMAP_23_OFFCENTER :951-958
-      vFace = (int)(y * 3.0f);
-      hFace = (int)(x * 2.0f);
-      x = x * 2.0f - (float)hFace;
-      y = y * 3.0f - (float)vFace;
-      face = hFace + (2 - vFace) * 2;
-      ftab = kFace23;
+    int face = 0, vFace, hFace;
+    const unsigned char(*ftab)[3] = kFace32;
+    bool spherical = false;  // q comes from (yaw, pitch) tables instead of a cube face
+    int col_idx = j;
+    switch (P.output_layout) {
+      case LAYOUT_CUBEMAP_32:  // :943-950
+        vFace = (int)(y * 2.0f);
+        hFace = (int)(x * 3.0f);
+        x = x * 3.0f - (float)hFace;
+        y = y * 2.0f - (float)vFace;
+        face = hFace + (1 - vFace) * 3;
+        break;
+      case LAYOUT_CUBEMAP_23_OFFCENTER:  // :951-958
+        vFace = (int)(y * 3.0f);
+        hFace = (int)(x * 2.0f);
+        x = x * 2.0f - (float)hFace;
+        y = y * 3.0f - (float)vFace;
+        face = hFace + (2 - vFace) * 2;
+        ftab = kFace23;
+        break;
+      case LAYOUT_EQUIRECT:  // :961-964, sinf/cosf at :1090-1097
+        spherical = true;
+        break;
+      case LAYOUT_BARREL:  // :965-977
+        if (x <= 0.8f) {
+          spherical = true;
+        } else {
+          vFace = (int)(y * 2.0f);
+          face = vFace == 1 ? 2 /*TOP*/ : 3 /*BOTTOM*/;
+          x = x * 5.0f - 4.0f;
+          y = y * 2.0f - (float)vFace;
+        }
+        break;
+      case LAYOUT_BARREL_SPLIT:  // :978-1015
+        if (3.0f * x <= 2.0f) {
+          vFace = (int)(y * 2.0f);
+          spherical = true;
+          col_idx = (vFace != 0 ? P.map_w : 0) + j;  // yaw depends on the half (vFace in {0, 1})
+        } else {
+          const int halfVFace = (int)(y * 4.0f);
+          face = (halfVFace == 1 || halfVFace == 3) ? 2 /*TOP*/ : 3 /*BOTTOM*/;
+          x = x * 3.0f - 2.0f;
+          switch (halfVFace) {
+            case 0:
+              y = y * 2.0f;
+              x = 1.0f - x;
+              y = (0.5f - y) * P.expand_coef;
+              break;
+            case 1:
+              y = y * 2.0f;
+              x = 1.0f - x;
+              y = 1.0f - P.expand_coef * (y - 0.5f);
+              break;
+            case 2:
+              y = y * 2.0f - 0.5f;
+              y = 1.0f - P.expand_coef * (1.0f - y);
+              break;
+            case 3:
+              y = y * 2.0f - 1.5f;
+              y = y * P.expand_coef;
+              break;
+            default:
+              break;
+          }
+        }
+        break;
+      default:  // LAYOUT_EAC_32 :1016-1027: the tan() warp of both face coordinates is tabulated
+        vFace = (int)(y * 2.0f);
+        hFace = (int)(x * 3.0f);
+        x = P.col_tab[j];
+        y = P.row_tab[i];
+        face = hFace + (1 - vFace) * 3;
+        break;
     }
     // x == 1.0 cannot occur for pixel centres, but keep indices in range for safety
     face = face < 0 ? 0 : (face > 5 ? 5 : face);
 
-    x = (x - 0.5f) * P.expand_coef + 0.5f;  // :1115-1116
-    y = (y - 0.5f) * P.expand_coef + 0.5f;
+    float qx, qy, qz;
+    if (spherical) {  // :1090-1100
+      const float sin_yaw = P.col_tab[2 * col_idx], cos_yaw = P.col_tab[2 * col_idx + 1];
+      const float sin_pitch = P.row_tab[2 * i], cos_pitch = P.row_tab[2 * i + 1];
+      qx = sin_yaw * cos_pitch;
+      qy = sin_pitch;
+      qz = cos_yaw * cos_pitch;
+    } else {
+      if (P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT) {  // :1102-1112
+        const float radius = (x - 0.5f) * (x - 0.5f) + (y - 0.5f) * (y - 0.5f);
+        if (radius > 0.25f * P.expand_coef * P.expand_coef) hasMapping = false;
+      }
+      x = (x - 0.5f) * P.expand_coef + 0.5f;  // :1115-1116
+      y = (y - 0.5f) * P.expand_coef + 0.5f;
 
-    const float* p = kP[ftab[face][0]];
-    const float* vx = kAxis[ftab[face][1]];
-    const float* vy = kAxis[ftab[face][2]];
-    float qx = p[0] + vx[0] * x + vy[0] * y;  // :1187-1189
-    float qy = p[1] + vx[1] * x + vy[1] * y;
-    float qz = p[2] + vx[2] * x + vy[2] * y;
+      const float* p = kP[ftab[face][0]];
+      const float* vx = kAxis[ftab[face][1]];
+      const float* vy = kAxis[ftab[face][2]];
+      qx = p[0] + vx[0] * x + vy[0] * y;  // :1187-1189
+      qy = p[1] + vx[1] * x + vy[1] * y;
+      qz = p[2] + vx[2] * x + vy[2] * y;
+    }
 
     if (P.offcenter) {  // :1192-1230
       float d = t360m::sqrt_rn(qx * qx + qy * qy + qz * qz);
@@ -255,13 +327,22 @@ __global__ __launch_bounds__(256) void mapgen_kernel(MapGenParams P, float2* __r
       // -atan2f(-tx/d, tz/d) / (M_PI * 2.0f) + 0.5f : division and sum in double (:880)
       float a = t360m::atan2_f32(div_rn(-tx, d), div_rn(tz, d));
       outX = (float)((double)(-a) / 6.283185307179586476925286766559 + 0.5);
+      if (P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT) {  // :881-886
+        const float hi = 1.0f - P.input_pixel_width * 0.5f;
+        const float lo = P.input_pixel_width * 0.5f;
+        outX = (hi < outX) ? hi : outX;  // std::min
+        outX = (outX < lo) ? lo : outX;  // std::max
+      }
       float s = t360m::asin_f32(div_rn(-ty, d));
       outY = (float)((double)s / 3.14159265358979323846 + 0.5);  // :887
     }
   }
 
-  // stereo re-pack (:1278-1300)
-  if (P.input_stereo == STEREO_FORMAT_TB) {
+  // stereo re-pack (:1278-1300); pixels without a mapping (outside the barrel caps) get (-1, 0)
+  if (!hasMapping) {
+    outX = -1.0f;
+    outY = 0.0f;
+  } else if (P.input_stereo == STEREO_FORMAT_TB) {
     outY = isRight ? (outY * 0.5f + 0.5f) : (outY * 0.5f);
   } else if (P.input_stereo == STEREO_FORMAT_LR) {
     outX = isRight ? (outX * 0.5f + 0.5f) : (outX * 0.5f);

@@ -285,9 +285,9 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     return false;
   }
   const int olay = (int)ctx_.output_layout;
-  if (!(olay == LAYOUT_CUBEMAP_32 || olay == LAYOUT_CUBEMAP_23_OFFCENTER || olay == LAYOUT_FLAT_FIXED)) {
-    printf("Could not generate map for plane %d. Error: output layout %d is not implemented on the "
-           "HIP path yet\n", idx, olay);
+  if (olay < 0 || olay >= LAYOUT_N) {
+    // reference transformPos default: branch (:1080-1083) -> generateMapForPlane fails (:539-543)
+    printf("Invalid layout type.\nFailed to find the mapping coordinate for point (0, 0)\n");
     return false;
   }
   if (ctx_.enable_low_pass_filter &&
@@ -343,6 +343,90 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     P.rot[6] = c1 * s2 * s3 - c3 * s1;
     P.rot[7] = c1 * c3 * s2 + s1 * s3;
     P.rot[8] = c1 * c2;
+  }
+
+  // Column / row tables of the layouts whose per-pixel libm calls depend on one coordinate only
+  // (t360_internal.h, MapGenParams::col_tab).  The front end below is transformPos :903-938 for
+  // one coordinate; every expression keeps the reference's types (float * M_PI is double).
+  if (olay == LAYOUT_EQUIRECT || olay == LAYOUT_BARREL || olay == LAYOUT_BARREL_SPLIT || olay == LAYOUT_EAC_32) {
+    const bool stereo_in = ctx_.input_stereo_format != STEREO_FORMAT_MONO;
+    auto front_x = [&](int j) {
+      float x = ((float)j + 0.5f) / (float)P.map_w;
+      if (stereo_in && ctx_.output_stereo_format == STEREO_FORMAT_LR) x = x > 0.5f ? (x - 0.5f) / 0.5f : x / 0.5f;
+      return x;
+    };
+    auto front_y = [&](int i) {
+      float y = ((float)i + 0.5f) / (float)P.map_h;
+      if (stereo_in && ctx_.output_stereo_format == STEREO_FORMAT_TB) {
+        if (y > 0.5f) {
+          y = (y - 0.5f) / 0.5f;
+          if (ctx_.vflip) y = 1.0f - y;
+        } else {
+          y = y / 0.5f;
+        }
+      }
+      return 1.0f - y;  // :936-938
+    };
+    const float e = ctx_.expand_coef;
+    std::vector<float> col, row;
+    if (olay == LAYOUT_EAC_32) {  // :1016-1027
+      col.resize((size_t)P.map_w);
+      row.resize((size_t)P.map_h);
+      for (int j = 0; j < P.map_w; j++) {
+        float x = front_x(j);
+        const int hFace = (int)(x * 3);
+        x = x * 3.0f - hFace;
+        col[(size_t)j] = (float)(std::tan((x - 0.5f) * M_PI * 0.5f) * 0.5f + 0.5f);
+      }
+      for (int i = 0; i < P.map_h; i++) {
+        float y = front_y(i);
+        const int vFace = (int)(y * 2);
+        y = y * 2.0f - vFace;
+        row[(size_t)i] = (float)(std::tan((y - 0.5f) * M_PI * 0.5f) * 0.5f + 0.5f);
+      }
+    } else {
+      const int halves = olay == LAYOUT_BARREL_SPLIT ? 2 : 1;
+      col.resize((size_t)P.map_w * 2 * halves);
+      row.resize((size_t)P.map_h * 2);
+      for (int h = 0; h < halves; h++)
+        for (int j = 0; j < P.map_w; j++) {
+          const float x = front_x(j);
+          float yaw;
+          if (olay == LAYOUT_EQUIRECT)
+            yaw = (float)((2.0f * x - 1.0f) * M_PI);  // :962
+          else if (olay == LAYOUT_BARREL)
+            yaw = (float)((2.5f * x - 1.0f) * e * M_PI);  // :967
+          else
+            yaw = (float)(((3.0f / 2.0f * x - 0.5f) * e - h + 1.0f) * M_PI);  // :981, h = vFace
+          const size_t o = ((size_t)h * P.map_w + j) * 2;
+          col[o] = sinf(yaw);  // :1094-1097: float arguments -> the float overloads
+          col[o + 1] = cosf(yaw);
+        }
+      for (int i = 0; i < P.map_h; i++) {
+        const float y = front_y(i);
+        float pitch;
+        if (olay == LAYOUT_EQUIRECT) {
+          pitch = (float)((y - 0.5f) * M_PI);  // :963
+        } else if (olay == LAYOUT_BARREL) {
+          pitch = (float)((y * 0.5f - 0.25f) * e * M_PI);  // :968
+        } else {
+          const int vFace = (int)(y * 2);
+          pitch = (float)((y - 0.25f - 0.5f * vFace) * e * M_PI);  // :982
+        }
+        row[(size_t)i * 2] = sinf(pitch);
+        row[(size_t)i * 2 + 1] = cosf(pitch);
+      }
+    }
+    if (!p.col_tab.reserve(col.size() * sizeof(float)) || !p.row_tab.reserve(row.size() * sizeof(float)))
+      return check(hipErrorOutOfMemory, "hipMalloc(tables)");
+    if (!check(hipMemcpyAsync(p.col_tab.as<void>(), col.data(), col.size() * sizeof(float), hipMemcpyHostToDevice, stream_),
+               "hipMemcpy(tables)") ||
+        !check(hipMemcpyAsync(p.row_tab.as<void>(), row.data(), row.size() * sizeof(float), hipMemcpyHostToDevice, stream_),
+               "hipMemcpy(tables)") ||
+        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+      return false;
+    P.col_tab = p.col_tab.as<float>();
+    P.row_tab = p.row_tab.as<float>();
   }
 
   const size_t n = (size_t)P.map_w * (size_t)P.map_h;

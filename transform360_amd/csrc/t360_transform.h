@@ -67,6 +67,7 @@ class VideoFrameTransform {
     int map_w = 0, map_h = 0;                      // scaled output size
     t360::DeviceBuffer map;                        // float2[map_h][map_w]
     t360::DeviceBuffer lut;                        // LutEntry[map_h][map_w]
+    t360::DeviceBuffer col_tab, row_tab;           // per-column / per-row libm values (MapGenParams)
     // low-pass
     t360::FilterConfig filter;
     t360::DeviceBuffer segs, taps_q8, taps_f32, taps_pk, tiles;
