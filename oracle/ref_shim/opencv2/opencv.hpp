@@ -14,7 +14,7 @@
  *                         bound to the oracle's restatement of OpenCV's arithmetic
  *                         (t360_oracle_cv.c) -- so oracle/_ref pins the ORCHESTRATION around
  *                         those calls, not OpenCV's arithmetic itself (PARITY UNPINNED there)
- *   cv::resize            INTER_AREA is not restated yet: throws
+ *   cv::resize            INTER_AREA shrink, bound to the oracle's restatement as well
  */
 #pragma once
 
@@ -33,6 +33,8 @@ void t360o_remap_rows(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t*
 int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep, uint8_t* dparent,
                         size_t dstep, int left, int top, int width, int height, const float* kx,
                         int kx_len, const float* ky, int ky_len);
+int t360o_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                      size_t dstep);
 }
 
 #define CV_8U 0
@@ -217,8 +219,14 @@ inline void sepFilter2D(const Mat& src, Mat& dst, int ddepth, const Mat& kernelX
                       kernelY.rows * kernelY.cols);
 }
 
-inline void resize(const Mat&, Mat&, Size, double, double, int) {
-  throw Exception("shim: cv::resize(INTER_AREA) is not restated (SURVEY.md 8f N4)");
+/* the reference calls resize(scaled, outputMat, Size(outputWidth, outputHeight), 0, 0, INTER_AREA)
+ * with a preallocated CV_8U destination of that size (VideoFrameTransform.cpp:770-776) */
+inline void resize(const Mat& src, Mat& dst, Size dsize, double fx, double fy, int interpolation) {
+  if (interpolation != INTER_AREA || fx != 0 || fy != 0) throw Exception("shim: only resize(..., 0, 0, INTER_AREA)");
+  if (src.type() != CV_8U || dst.type() != CV_8U) throw Exception("shim: resize only for CV_8U");
+  if (dst.cols != dsize.width || dst.rows != dsize.height) throw Exception("shim: resize needs a preallocated dst");
+  if (!t360o_resize_area(src.data, src.cols, src.rows, src.step, dst.data, dst.cols, dst.rows, dst.step))
+    throw Exception("shim: cv::resize(INTER_AREA) enlargement is not restated");
 }
 
 }  // namespace cv

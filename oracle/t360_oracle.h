@@ -103,6 +103,11 @@ int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep,
                         const float* kx, int kx_len, const float* ky, int ky_len);
 int t360o_kernel_type(const float* k, int len); /* cv::getKernelType with the default anchor */
 
+/* cv::resize(..., INTER_AREA) for CV_8UC1, shrinking only (VideoFrameTransform.cpp:770-776);
+ * returns 0 for requests it does not restate (enlargement). */
+int t360o_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                      size_t dstep);
+
 /* ---- frame path with the reference's call protocol (t360_oracle_frame.c) ---- */
 typedef struct T360Oracle T360Oracle;
 

@@ -348,3 +348,130 @@ int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep, uin
   free(rows);
   return 0;
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * cv::resize(src, dst, dsize, 0, 0, INTER_AREA) for CV_8UC1, the shrinking case the reference
+ * uses for its supersample-then-decimate antialiasing (VideoFrameTransform.cpp:770-776).
+ * Restated from OpenCV 4.x modules/imgproc/src/resize.cpp (PARITY UNPINNED, like the rest of
+ * this file):
+ *   scale_x = 1 / ((double)dw / sw), scale_y likewise; only scale >= 1 on both axes is restated
+ *   (INTER_AREA enlargement is a different, bilinear-like code path; returns 0 = unsupported).
+ *   a) both scales integers (|scale - (int)scale| < DBL_EPSILON), "ResizeAreaFast":
+ *        2 x 2      : (a + b + c + d + 2) >> 2                       (ResizeAreaFastVec / its scalar tail)
+ *        otherwise  : saturate_cast<uchar>(int_sum * (1.f / area))   float multiply, cvRound (half-even)
+ *      the source is an exact multiple of the destination here, so the partial-cell tail of the
+ *      OpenCV loop is never reached.
+ *   b) otherwise, "ResizeArea": per axis a DecimateAlpha table (computeResizeAreaTab);
+ *        buf[dx] = SUM_k S[si_k] * alpha_k  (float, table order),  sum[dx] = SUM_j beta_j * buf_j[dx]
+ *        (float, row order, first term assigned), D = saturate_cast<uchar>(sum).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int si, di;
+  float alpha;
+} DecimateAlpha;
+
+static int resize_area_tab(int ssize, int dsize, double scale, DecimateAlpha* tab) {
+  int k = 0;
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale;
+    double fsx2 = fsx1 + scale;
+    double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1; /* std::min(scale, ssize - fsx1) */
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    if (sx1 - fsx1 > 1e-3) {
+      tab[k].di = dx;
+      tab[k].si = sx1 - 1;
+      tab[k++].alpha = (float)((sx1 - fsx1) / cellWidth);
+    }
+    for (int sx = sx1; sx < sx2; sx++) {
+      tab[k].di = dx;
+      tab[k].si = sx;
+      tab[k++].alpha = (float)(1.0 / cellWidth);
+    }
+    if (fsx2 - sx2 > 1e-3) {
+      double a = fsx2 - sx2;
+      a = a < 1.0 ? a : 1.0;
+      a = a < cellWidth ? a : cellWidth;
+      tab[k].di = dx;
+      tab[k].si = sx2;
+      tab[k++].alpha = (float)(a / cellWidth);
+    }
+  }
+  return k;
+}
+
+int t360o_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                      size_t dstep) {
+  if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return 0;
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
+  if (!(scale_x >= 1 && scale_y >= 1)) return 0; /* enlargement: not restated */
+  const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y); /* saturate_cast<int>(double) */
+  const int fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+  if (fast && (size_t)iscale_x * dw == (size_t)sw && (size_t)iscale_y * dh == (size_t)sh) {
+    const int area = iscale_x * iscale_y;
+    const float scale = 1.f / area;
+    for (int dy = 0; dy < dh; dy++) {
+      uint8_t* D = dst + (size_t)dy * dstep;
+      for (int dx = 0; dx < dw; dx++) {
+        int sum = 0;
+        for (int sy = 0; sy < iscale_y; sy++) {
+          const uint8_t* S = src + (size_t)(dy * iscale_y + sy) * sstep + (size_t)dx * iscale_x;
+          for (int sx = 0; sx < iscale_x; sx++) sum += S[sx];
+        }
+        if (iscale_x == 2 && iscale_y == 2) {
+          D[dx] = (uint8_t)((sum + 2) >> 2);
+        } else {
+          long v = lrintf((float)sum * scale);
+          D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+      }
+    }
+    return 1;
+  }
+  DecimateAlpha* xt = (DecimateAlpha*)malloc(sizeof(DecimateAlpha) * (size_t)sw * 2);
+  DecimateAlpha* yt = (DecimateAlpha*)malloc(sizeof(DecimateAlpha) * (size_t)sh * 2);
+  float* buf = (float*)malloc(sizeof(float) * (size_t)dw * 2);
+  if (!xt || !yt || !buf) {
+    free(xt);
+    free(yt);
+    free(buf);
+    return 0;
+  }
+  float* sum = buf + dw;
+  const int nx = resize_area_tab(sw, dw, scale_x, xt);
+  const int ny = resize_area_tab(sh, dh, scale_y, yt);
+  int prev_dy = yt[0].di;
+  for (int dx = 0; dx < dw; dx++) sum[dx] = 0.f;
+  for (int j = 0; j < ny; j++) {
+    const float beta = yt[j].alpha;
+    const int dy = yt[j].di;
+    const uint8_t* S = src + (size_t)yt[j].si * sstep;
+    for (int dx = 0; dx < dw; dx++) buf[dx] = 0.f;
+    for (int k = 0; k < nx; k++) buf[xt[k].di] += S[xt[k].si] * xt[k].alpha;
+    if (dy != prev_dy) {
+      uint8_t* D = dst + (size_t)prev_dy * dstep;
+      for (int dx = 0; dx < dw; dx++) {
+        long v = lrintf(sum[dx]);
+        D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        sum[dx] = beta * buf[dx];
+      }
+      prev_dy = dy;
+    } else {
+      for (int dx = 0; dx < dw; dx++) sum[dx] += beta * buf[dx];
+    }
+  }
+  {
+    uint8_t* D = dst + (size_t)prev_dy * dstep;
+    for (int dx = 0; dx < dw; dx++) {
+      long v = lrintf(sum[dx]);
+      D[dx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+  free(xt);
+  free(yt);
+  free(buf);
+  return 1;
+}

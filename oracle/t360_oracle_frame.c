@@ -296,11 +296,29 @@ int t360o_transformFramePlane(T360Oracle* o, const uint8_t* in, uint8_t* out, in
     int ntasks = (outH + a.rows_per_task - 1) / a.rows_per_task;
     run_tasks(threads, ntasks, remap_task, &a);
   } else {
-    /* supersample + cv::resize(INTER_AREA) (:759-776): SURVEY.md 8f row N4, not restated yet */
-    printf("Could not transform the plane %d. Error: scaled output not supported by the oracle\n",
-           imagePlaneIdx);
-    free(blurred);
-    return 0;
+    /* supersample + cv::resize(INTER_AREA) (:759-776): remap into a map-sized image that starts
+     * as Scalar(mapIdx ? 128 : 0), then shrink it into the output plane */
+    uint8_t* scaled = (uint8_t*)malloc((size_t)p->map_w * (size_t)p->map_h);
+    if (!scaled) {
+      free(blurred);
+      return 0;
+    }
+    memset(scaled, mapIdx ? 128 : 0, (size_t)p->map_w * (size_t)p->map_h);
+    RemapArgs a = {src, inW, inH, sstep, scaled, p->map_w, p->map_h, (size_t)p->map_w, p->map, interp, border, 0};
+    int stripes = threads > 1 ? threads * 4 : 1;
+    if (stripes > p->map_h) stripes = p->map_h;
+    a.rows_per_task = (p->map_h + stripes - 1) / stripes;
+    int ntasks = (p->map_h + a.rows_per_task - 1) / a.rows_per_task;
+    run_tasks(threads, ntasks, remap_task, &a);
+    int ok = t360o_resize_area(scaled, p->map_w, p->map_h, (size_t)p->map_w, out, outW, outH, (size_t)outStride);
+    free(scaled);
+    if (!ok) {
+      /* the reference would run cv::resize's enlargement path here, which is not restated */
+      printf("Could not transform the plane %d. Error: INTER_AREA enlargement is not restated by the oracle\n",
+             imagePlaneIdx);
+      free(blurred);
+      return 0;
+    }
   }
   free(blurred);
   return 1;

@@ -86,6 +86,19 @@ FRAME_CASES = {
     "tiny": (dict(enable_low_pass_filter=0), (64, 32, 48, 32), 3, 5),
 }
 
+# supersample + cv::resize(INTER_AREA): 2x2 (shift rounding), other integer
+# factors (float scale), fractional factors (DecimateAlpha tables)
+SUPERSAMPLE_FRAME_CASES = {
+    "supersample_2x2": (dict(enable_low_pass_filter=0, width_scale_factor=2.0, height_scale_factor=2.0),
+                        (1024, 512, 384, 256), 0, 0),
+    "supersample_3x2_linear": (dict(enable_low_pass_filter=0, width_scale_factor=3.0, height_scale_factor=2.0,
+                                    interpolation_alg=LINEAR), (1024, 512, 384, 256), 32, 16),
+    "supersample_1p5": (dict(enable_low_pass_filter=0, width_scale_factor=1.5, height_scale_factor=1.5),
+                        (1024, 512, 384, 256), 0, 0),
+    "supersample_1p3x2p7_barrel": (dict(enable_low_pass_filter=0, width_scale_factor=1.3, height_scale_factor=2.7,
+                                        output_layout=LAYOUT_BARREL), (1024, 512, 640, 256), 0, 0),
+}
+
 LAYOUT_FRAME_CASES = {
     "barrel_cubic": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_BARREL), (1024, 512, 640, 256), 0, 0),
     "barrel_split_linear": (dict(enable_low_pass_filter=0, output_layout=LAYOUT_BARREL_SPLIT, interpolation_alg=LINEAR),

@@ -99,7 +99,7 @@ def main():
         r.close()
 
     frames = {}
-    for name, (ov, dims, pin, pout) in {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES}.items():
+    for name, (ov, dims, pin, pout) in {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES, **cases.SUPERSAMPLE_FRAME_CASES}.items():
         in_w, in_h, out_w, out_h = dims
         r = O.Ref(cases.make_ctx(ov))
         assert r.generateMapForPlane(*dims, 0)

@@ -42,7 +42,7 @@ def padded_cuda(h, w, pad, fill):
 
 # ---------------------------------------------------------------- projection kernel
 ALL_MAPS = {**cases.MAP_CASES, **cases.LAYOUT_MAP_CASES}
-ALL_FRAMES = {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES}
+ALL_FRAMES = {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES, **cases.SUPERSAMPLE_FRAME_CASES}
 
 
 @pytest.mark.parametrize("name", sorted(ALL_MAPS))
@@ -68,9 +68,9 @@ def test_map_bit_exact(name, T, oracle_mod, golden):
 
 
 def test_unsupported_request_is_refused_not_faked(T):
-    # supersampled maps are not on the HIP path yet: the call must fail, not fall
-    # back to anything else
-    with T.VideoFrameTransform(filter_defaults(width_scale_factor=2.0, height_scale_factor=2.0)) as t:
+    # INTER_AREA enlargement (scale factor < 1) is a different OpenCV code path that is not on the HIP
+    # path: the call must fail, not fall back to anything else
+    with T.VideoFrameTransform(filter_defaults(width_scale_factor=0.5, height_scale_factor=0.5)) as t:
         ok = t.generateMapForPlane(1024, 512, 384, 256, 0)
         src = dev(np.zeros((512, 1024), np.uint8))
         dst = dev(np.zeros((256, 384), np.uint8))

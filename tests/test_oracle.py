@@ -8,7 +8,7 @@ from tests import cases
 from transform360_amd.abi import CUBIC, LANCZOS4, LINEAR, NEAREST, filter_defaults
 
 ALL_MAPS = {**cases.MAP_CASES, **cases.LAYOUT_MAP_CASES}
-ALL_FRAMES = {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES}
+ALL_FRAMES = {**cases.FRAME_CASES, **cases.LAYOUT_FRAME_CASES, **cases.SUPERSAMPLE_FRAME_CASES}
 BIG = ("cfg4_luma", "cfg4_chroma")
 
 

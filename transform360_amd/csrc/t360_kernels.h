@@ -100,4 +100,23 @@ struct LowpassArgs {
 };
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
 
+// ---- INTER_AREA shrink of the supersampled plane (t360_resize.hip) ----
+struct ResizeArgs {
+  const uint8_t* src;
+  int64_t src_frame_bytes;
+  int sstride, sw, sh;
+  uint8_t* dst;
+  int64_t dst_frame_bytes;
+  int dstride, dw, dh;
+  int iscale_x, iscale_y;  // > 0: integer factors (ResizeAreaFast); 0: table driven (ResizeArea)
+  float inv_area;          // 1.f / (iscale_x * iscale_y)
+  const int* xofs;         // [dw + 1] ranges into x_si / x_alpha
+  const int* x_si;
+  const float* x_alpha;
+  const int* yofs;         // [dh + 1]
+  const int* y_si;
+  const float* y_alpha;
+};
+hipError_t launch_resize_area(const ResizeArgs& a, int nframes, hipStream_t stream);
+
 }  // namespace t360

@@ -522,8 +522,69 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   }
   // host vectors above go out of scope: finish the uploads (init-time only)
   if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  if (!buildResizePlan(p)) return false;
   p.valid = true;
   return true;
+}
+
+// cv::resize(..., INTER_AREA) from the warp-map size to the output size (reference :770-776);
+// which of OpenCV's code paths applies and, for fractional factors, its DecimateAlpha tables
+// (resize.cpp computeResizeAreaTab, evaluated in double like OpenCV does).
+bool VideoFrameTransform::buildResizePlan(PlaneState& p) {
+  PlaneState::ResizePlan& r = p.resize;
+  r.needed = p.map_w != p.out_w || p.map_h != p.out_h;
+  r.supported = false;
+  r.iscale_x = r.iscale_y = 0;
+  if (!r.needed) return true;
+  const int sw = p.map_w, sh = p.map_h, dw = p.out_w, dh = p.out_h;
+  if (dw <= 0 || dh <= 0) return true;
+  const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+  if (!(scale_x >= 1 && scale_y >= 1)) return true;  // enlargement: a different OpenCV path, refused at run time
+  r.supported = true;
+  const int ix = (int)std::lrint(scale_x), iy = (int)std::lrint(scale_y);  // saturate_cast<int>(double)
+  if (std::fabs(scale_x - ix) < DBL_EPSILON && std::fabs(scale_y - iy) < DBL_EPSILON && (int64_t)ix * dw == sw &&
+      (int64_t)iy * dh == sh) {
+    r.iscale_x = ix;
+    r.iscale_y = iy;
+    return true;
+  }
+  auto build = [](int ssize, int dsize, double scale, std::vector<int>* ofs, std::vector<int>* si, std::vector<float>* al) {
+    ofs->assign((size_t)dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+      (*ofs)[(size_t)dx] = (int)si->size();
+      const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+      const double cellWidth = std::min(scale, ssize - fsx1);
+      int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+      sx2 = std::min(sx2, ssize - 1);
+      sx1 = std::min(sx1, sx2);
+      if (sx1 - fsx1 > 1e-3) {
+        si->push_back(sx1 - 1);
+        al->push_back((float)((sx1 - fsx1) / cellWidth));
+      }
+      for (int sx = sx1; sx < sx2; sx++) {
+        si->push_back(sx);
+        al->push_back((float)(1.0 / cellWidth));
+      }
+      if (fsx2 - sx2 > 1e-3) {
+        si->push_back(sx2);
+        al->push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth));
+      }
+    }
+    (*ofs)[(size_t)dsize] = (int)si->size();
+  };
+  std::vector<int> xofs, xsi, yofs, ysi;
+  std::vector<float> xal, yal;
+  build(sw, dw, scale_x, &xofs, &xsi, &xal);
+  build(sh, dh, scale_y, &yofs, &ysi, &yal);
+  auto up = [&](t360::DeviceBuffer& b, const void* src, size_t bytes) {
+    if (!b.reserve(bytes ? bytes : 4)) return check(hipErrorOutOfMemory, "hipMalloc(resize tables)");
+    return bytes == 0 || check(hipMemcpyAsync(b.as<void>(), src, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpy(resize tables)");
+  };
+  if (!up(r.xofs, xofs.data(), xofs.size() * 4) || !up(r.x_si, xsi.data(), xsi.size() * 4) ||
+      !up(r.x_alpha, xal.data(), xal.size() * 4) || !up(r.yofs, yofs.data(), yofs.size() * 4) ||
+      !up(r.y_si, ysi.data(), ysi.size() * 4) || !up(r.y_alpha, yal.data(), yal.size() * 4))
+    return false;
+  return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
 // b directly continues a to the right with the same band and bit-identical kernels
@@ -690,6 +751,74 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
   return check(launch_lowpass(a, n_frames, stream_), "low-pass launch");
 }
 
+// transformPlane's needResize branch (VideoFrameTransform.cpp:759-776): gather into a warp-map-sized
+// image that starts as Scalar(mapIdx ? 128 : 0), then cv::resize(INTER_AREA) into the output plane.
+bool VideoFrameTransform::runPlanesScaled(const PlaneJob* jobs, int njobs, int n_frames) {
+  std::vector<PlaneJob> inner(jobs, jobs + njobs);
+  std::vector<size_t> offs((size_t)njobs);
+  std::vector<int> strides((size_t)njobs);
+  size_t total = 0;
+  for (int k = 0; k < njobs; k++) {
+    const PlaneState& p = planes_[jobs[k].idx];
+    if (jobs[k].out_w != p.out_w || jobs[k].out_h != p.out_h || !p.resize.needed) {
+      // the reference resizes to whatever size it is handed; the plan here is for the size given
+      // to generateMapForPlane, which is what the filter passes (vf_transform360.c:368-397)
+      printf("Could not transform the plane %d. Error: output size differs from the one the map was generated for\n",
+             jobs[k].image_plane);
+      return false;
+    }
+    if (!p.resize.supported) {
+      printf("Could not transform the plane %d. Error: INTER_AREA enlargement (scale factor < 1) is not implemented "
+             "on the HIP path\n", jobs[k].image_plane);
+      return false;
+    }
+    strides[(size_t)k] = (p.map_w + 255) & ~255;
+    offs[(size_t)k] = total;
+    total += (size_t)strides[(size_t)k] * p.map_h * (size_t)n_frames;
+  }
+  if (!scaled_.reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(scaled)");
+  for (int k = 0; k < njobs; k++) {
+    const PlaneState& p = planes_[jobs[k].idx];
+    PlaneJob& j = inner[(size_t)k];
+    j.out = scaled_.as<uint8_t>() + offs[(size_t)k];
+    j.out_w = p.map_w;
+    j.out_h = p.map_h;
+    j.out_stride = strides[(size_t)k];
+    j.out_frame_bytes = (int64_t)j.out_stride * p.map_h;
+    if (!check(launch_fill_plane(j.out, j.out_frame_bytes, j.out_w, j.out_h, j.out_stride, j.idx ? 128 : 0, n_frames, stream_),
+               "fill launch"))
+      return false;
+  }
+  if (!runPlanes(inner.data(), njobs, n_frames)) return false;
+  for (int k = 0; k < njobs; k++) {
+    PlaneState& p = planes_[jobs[k].idx];
+    const PlaneJob& j = inner[(size_t)k];
+    ResizeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = j.out;
+    a.src_frame_bytes = j.out_frame_bytes;
+    a.sstride = j.out_stride;
+    a.sw = p.map_w;
+    a.sh = p.map_h;
+    a.dst = jobs[k].out;
+    a.dst_frame_bytes = jobs[k].out_frame_bytes;
+    a.dstride = jobs[k].out_stride;
+    a.dw = jobs[k].out_w;
+    a.dh = jobs[k].out_h;
+    a.iscale_x = p.resize.iscale_x;
+    a.iscale_y = p.resize.iscale_y;
+    a.inv_area = p.resize.iscale_x > 0 ? 1.f / (float)(p.resize.iscale_x * p.resize.iscale_y) : 0.f;
+    a.xofs = p.resize.xofs.as<int>();
+    a.x_si = p.resize.x_si.as<int>();
+    a.x_alpha = p.resize.x_alpha.as<float>();
+    a.yofs = p.resize.yofs.as<int>();
+    a.y_si = p.resize.y_si.as<int>();
+    a.y_alpha = p.resize.y_alpha.as<float>();
+    if (!check(launch_resize_area(a, n_frames, stream_), "resize launch")) return false;
+  }
+  return true;
+}
+
 // reference VideoFrameTransform::transformPlane (VideoFrameTransform.cpp:707-794), for a set of
 // planes of a batch of frames: [low-pass each plane] -> gather.  Bicubic planes whose buffers are
 // 16-byte friendly are gathered by ONE fused launch of the DMA-ring kernel.
@@ -703,11 +832,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   }
   for (int k = 0; k < njobs; k++) {
     const PlaneState& p = planes_[jobs[k].idx];
-    if (jobs[k].out_h != p.map_h || jobs[k].out_w != p.map_w) {
-      printf("Could not transform the plane %d. Error: supersampled output (width/height_scale_factor != 1, "
-             "cv::resize INTER_AREA) is not implemented on the HIP path yet\n", jobs[k].image_plane);
-      return false;
-    }
+    if (jobs[k].out_h != p.map_h || jobs[k].out_w != p.map_w) return runPlanesScaled(jobs, njobs, n_frames);  // :735-737
   }
 
   // ---- stage 1: segmented low-pass into the scratch planes (filterPlane, :621-704) ----

@@ -68,6 +68,12 @@ class VideoFrameTransform {
     t360::DeviceBuffer map;                        // float2[map_h][map_w]
     t360::DeviceBuffer lut;                        // LutEntry[map_h][map_w]
     t360::DeviceBuffer col_tab, row_tab;           // per-column / per-row libm values (MapGenParams)
+    // INTER_AREA shrink map_w x map_h -> out_w x out_h (only when the scale factors are not 1)
+    struct ResizePlan {
+      bool needed = false, supported = false;
+      int iscale_x = 0, iscale_y = 0;
+      t360::DeviceBuffer xofs, x_si, x_alpha, yofs, y_si, y_alpha;
+    } resize;
     // low-pass
     t360::FilterConfig filter;
     t360::DeviceBuffer segs, taps_q8, taps_f32, taps_pk, tiles;
@@ -98,6 +104,8 @@ class VideoFrameTransform {
     int image_plane;  // imagePlaneIndex (messages only, as in the reference)
   };
   bool runPlanes(const PlaneJob* jobs, int njobs, int n_frames);
+  bool runPlanesScaled(const PlaneJob* jobs, int njobs, int n_frames);
+  bool buildResizePlan(PlaneState& p);
   bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
                   int imagePlaneIndex);
@@ -120,5 +128,6 @@ class VideoFrameTransform {
   int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit1 register cap, bit2 no loader wave
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
+  t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
 };
