@@ -107,7 +107,10 @@ struct __attribute__((aligned(16))) TileDesc {
   int16_t cpr;        // 16-byte chunks per box row (row pitch in LDS = cpr * 16 bytes)
   int16_t rows;       // box rows
   int32_t tlut;       // first word of this tile in the box-relative LUT
-  int32_t pad[2];
+  int16_t cpr_src;    // chunks per row that hold source bytes; columns cpr_src..cpr-1 are LDS padding that
+                      // moves consecutive rows onto different banks (their lanes re-read chunk 0)
+  int16_t pad16;
+  int32_t pad;
 };
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 

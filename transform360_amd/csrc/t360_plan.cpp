@@ -71,6 +71,8 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   // 128x8 strips give ~330-byte row fragments (better for HBM) but measured ~4 % slower end to end
   // while the kernel is VALU-issue-bound; opt-in until that changes (DESIGN.md, round-1 notes)
   const bool allow_strips = getenv("T360_STRIPS") != nullptr;
+  const int pad_mode = getenv("T360_PAD") ? atoi(getenv("T360_PAD")) : 1;
+  int cpr_hist[64] = {0};
   auto emit = [&](const Box& bx, int kind, int tox, int toy, int ew, int eh) {
     TileDesc t{};
     t.ox = (int16_t)tox;
@@ -79,7 +81,24 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
     t.flags = (int16_t)((bx.seam_shift ? kTileSeamShift : 0) | ((tox + ew > dw || toy + eh > dh) ? kTilePartial : 0));
     t.x0 = bx.x0;
     t.y0 = bx.y0;
-    t.cpr = (int16_t)bx.cpr;
+    int cpr = bx.cpr;
+    if (pad_mode && kind != kTileDirect16) {
+      // LDS row pitch = 16*cpr bytes = 4*cpr banks.  The lanes of one output row drift over 2-3 source
+      // rows; with a pitch near a multiple of 128 bytes those rows land on the same banks (57 % of
+      // the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).  Padding columns (never fetched
+      // from HBM) put consecutive rows 8..24 banks apart.
+      int want = cpr;
+      if (pad_mode == 1)
+        while ((want & 7) == 7 || (want & 7) == 0 || (want & 7) == 1) want++;
+      else if (pad_mode == 2)
+        while ((want & 7) != 4) want++;
+      else
+        while ((want & 7) < 3 || (want & 7) > 5) want++;
+      if ((int64_t)want * bx.rows <= (int64_t)max_chunks && want * kStageChunk <= kStageMaxCols) cpr = want;
+    }
+    cpr_hist[cpr < 64 ? cpr : 63]++;
+    t.cpr = (int16_t)cpr;
+    t.cpr_src = (int16_t)bx.cpr;
     t.rows = (int16_t)bx.rows;
     t.tlut = (int32_t)tlut_words;
     if (kind == kTileDirect16) {
@@ -88,7 +107,7 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
       return;
     }
     tlut_words += kind == kTileStaged16 ? 256 : 1024;
-    staged_bytes += (int64_t)bx.cpr * kStageChunk * bx.rows;
+    staged_bytes += (int64_t)cpr * kStageChunk * bx.rows;
     (kind == kTileStaged16 ? n16 : kind == kTileStaged32 ? n32 : nstrip)++;
     tiles.push_back(t);
   };
@@ -165,6 +184,12 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
            "%d direct, %.2f MB staged per plane (%.2fx the source plane)\n",
            dw, dh, sw, sh, plan->ntiles, nstrip, n32, n16, ndirect, staged_bytes / 1e6,
            (double)staged_bytes / ((double)sw * sh));
+  if (getenv("T360_VERBOSE")) {
+    printf("transform360:   chunks per row (16 B each): ");
+    for (int c = 0; c < 64; c++)
+      if (cpr_hist[c]) printf("%d:%d ", c, cpr_hist[c]);
+    printf("\n");
+  }
   return true;
 }
 

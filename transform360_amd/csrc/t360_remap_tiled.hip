@@ -315,7 +315,8 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
     if (j < nj) {  // wave-uniform
       int q = lane + 64 * (which + j * nloaders);
       q = q < g.nch ? q : 0;
-      const int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
+      int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
+      if (cc >= (int)t.cpr_src) r = cc = 0;  // padding column
       const int sy = wrap_coord(t.y0 + r, pl.sh);
       int sx = t.x0 + cc * kStageChunk;  // multiple of 16; the plane width is a multiple of 16 here
       if (sx < 0)
@@ -449,7 +450,8 @@ __device__ __forceinline__ void self_loading_waves(const TiledArgs& a, const Til
     if (j < nj) {  // wave-uniform
       int q = lane + 64 * (wave + 4 * j);
       q = q < g.nch ? q : 0;  // lanes past the end of the box re-read chunk 0 into the slot's padding
-      const int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
+      int r = (int)(((uint32_t)q * inv) >> 16), cc = q - r * (int)t.cpr;
+      if (cc >= (int)t.cpr_src) r = cc = 0;  // padding column
       const int sy = wrap_coord(t.y0 + r, pl.sh);
       int sx = t.x0 + cc * kStageChunk;
       if (sx < 0)
@@ -572,6 +574,77 @@ __global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_cubic_
   }
 }
 
+// ---- persistent variant: one workgroup per resident slot, work pulled from per-XCD queues ------
+// The grid-per-tile launch pays a workgroup turnover (~2-3 us between a workgroup's end and its
+// successor's first instruction, measured with T360_TRACE) for every 16 frames of one tile, and
+// its tail is a whole wave of workgroups.  Here a workgroup stays resident and pulls
+// (frame group, tile) items: XCD x owns the tile range xcd_contiguous() gives it (neighbouring
+// tiles share their source halo in that XCD's L2) and walks it frame group by frame group; when
+// its own queue is empty it takes items from the other XCDs' queues, so the tail shrinks to one item.
+template <int VARIANT>
+__global__ __launch_bounds__(512, 1) void remap_tiled_cubic_persist_kernel(TiledArgs a) {
+  constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
+  extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
+  __shared__ int next_item[2];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ngroups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int my_xcd = (int)(xcc & 7);
+  const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+  int victim = 0;  // how many queues (starting with my own) are already known to be empty
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int got = -1, got_xcd = 0;
+      while (victim < 8) {
+        const int x = (my_xcd + victim) & 7;
+        const int len = q + (x < rem ? 1 : 0);
+        const int li = atomicAdd(a.work_counters + x, 1);
+        if (li < len * ngroups) {
+          got = li;
+          got_xcd = x;
+          break;
+        }
+        victim++;
+      }
+      next_item[0] = got;
+      next_item[1] = got_xcd;
+    }
+    __syncthreads();  // item boundary: everyone has also left the ring
+    const int li = __builtin_amdgcn_readfirstlane(next_item[0]);
+    const int x = __builtin_amdgcn_readfirstlane(next_item[1]);
+    __syncthreads();
+    if (li < 0) break;
+    const int len = q + (x < rem ? 1 : 0);
+    const int start = x * q + (x < rem ? x : rem);
+    const int g = li / len;
+    int b = start + (li - g * len);
+    TiledPlane pl = a.plane[0];
+    if (a.nplanes > 1 && b >= pl.ntiles) {
+      b -= pl.ntiles;
+      pl = a.plane[1];
+      if (a.nplanes > 2 && b >= pl.ntiles) {
+        b -= pl.ntiles;
+        pl = a.plane[2];
+        if (a.nplanes > 3 && b >= pl.ntiles) {
+          b -= pl.ntiles;
+          pl = a.plane[3];
+        }
+      }
+    }
+    const TileDesc t = pl.tiles[b];
+    const int f0 = g * a.frames_per_block;
+    const int f1 = min(f0 + a.frames_per_block, a.nframes);
+    if (wave >= kLoaderWave) {
+      loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
+    } else if (t.kind == kTileStaged16) {
+      consumer_waves<1, GROUP>(a, pl, t, lds, f0, f1);
+    } else {
+      consumer_waves<4, GROUP>(a, pl, t, lds, f0, f1);
+    }
+  }
+}
+
 // ===================== variant 2: chunks staged through registers ============================
 // For planes whose base / stride / width are not 16-byte friendly: chunks that are not one
 // aligned dwordx4 are assembled byte by byte with BORDER_WRAP.
@@ -607,8 +680,9 @@ __device__ __forceinline__ void staged_tile_regs(const TiledArgs& a, const Tiled
     goff[c] = 0;
     fast[c] = false;
     if (q < nch) {
-      const int r = q / (int)t.cpr, cc = q - r * (int)t.cpr;
+      int r = q / (int)t.cpr, cc = q - r * (int)t.cpr;
       loff[c] = q * kStageChunk;
+      if (cc >= (int)t.cpr_src) r = cc = 0;  // padding column
       const int sy = wrap_coord(t.y0 + r, pl.sh);
       int sx = t.x0 + cc * kStageChunk;
       if (sx + kStageChunk <= 0)
@@ -742,6 +816,29 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
     else
       hipLaunchKernelGGL(remap_tiled_cubic_self_kernel<0>, dim3(a.total_tiles, groups, 1), dim3(256), (size_t)a.ring_bytes,
                          stream, a);
+    return hipGetLastError();
+  }
+  if (a.variant & 8) {
+    // persistent workgroups: a.work_counters (8 ints) must be zero at launch
+    if (!a.work_counters || a.persist_slots <= 0) return hipErrorInvalidValue;
+    static int configured_persist = 0;
+    if (a.ring_bytes > 60 * 1024 && configured_persist < a.ring_bytes) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_persist_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_persist_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
+      if (e != hipSuccess) return e;
+      configured_persist = a.ring_bytes;
+    }
+    const int items = a.total_tiles * groups;
+    const int grid = items < a.persist_slots ? items : a.persist_slots;
+    TiledArgs p = a;
+    p.trace = nullptr;  // trace slots are indexed by blockIdx
+    if (a.variant & 1)
+      hipLaunchKernelGGL(remap_tiled_cubic_persist_kernel<1>, dim3(grid), dim3(256 + 64 * nload), (size_t)a.ring_bytes, stream, p);
+    else
+      hipLaunchKernelGGL(remap_tiled_cubic_persist_kernel<0>, dim3(grid), dim3(256 + 64 * nload), (size_t)a.ring_bytes, stream, p);
     return hipGetLastError();
   }
   switch (a.variant & 3) {

@@ -186,7 +186,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
   }
   if (getenv("T360_NO_DMA")) use_dma_ = false;
-  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 7;
+  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 15;
   if (const char* e = getenv("T360_LOADERS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) loader_waves_ = v;
@@ -958,6 +958,18 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       if (trace.reserve(nwg * 8 * sizeof(unsigned long long)) &&
           hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
         fused.trace = trace.as<unsigned long long>();
+    }
+    if (fused.variant & 8) {
+      if (persist_slots_ <= 0) {
+        hipDeviceProp_t prop;
+        if (!check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return false;
+        const int per_cu = getenv("T360_PERSIST_PER_CU") ? atoi(getenv("T360_PERSIST_PER_CU")) : 4;
+        persist_slots_ = prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4);
+      }
+      if (!work_counters_.reserve(8 * sizeof(int))) return check(hipErrorOutOfMemory, "hipMalloc(counters)");
+      if (!check(hipMemsetAsync(work_counters_.as<void>(), 0, 8 * sizeof(int), stream_), "hipMemsetAsync")) return false;
+      fused.work_counters = work_counters_.as<int>();
+      fused.persist_slots = persist_slots_;
     }
     if (!check(launch_remap_tiled_cubic_dma(fused, stream_), "tiled remap launch")) return false;
     if (fused.trace) {

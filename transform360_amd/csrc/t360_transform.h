@@ -128,6 +128,8 @@ class VideoFrameTransform {
   int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit1 register cap, bit2 no loader wave
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
+  t360::DeviceBuffer work_counters_;  // item queues of the persistent gather kernel (8 ints)
+  int persist_slots_ = 0;             // resident workgroup slots of the device for that kernel
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
 };
