@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- \
     python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --frames $FRAMES > "$OUT/trace.log" 2>&1
 cp "$OUT/trace/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_kernel_stats.csv" 2>/dev/null
-tail -1 "$OUT/trace.log" > "$R/profiles/${TAG}_bench_under_rocprof.json"
+grep -h "^{\"metric\"" "$OUT/trace.log" | tail -1 > "$R/profiles/${TAG}_bench_under_rocprof.json"
 cd "$R" && PMC_MEM=1 tools/prof_pmc.sh "$OUT/pmc" --frames $FRAMES > /dev/null 2>&1
 cp "$OUT/pmc/summary.txt" "$R/profiles/${TAG}_pmc_summary.txt"
 python tools/make_traffic.py "$OUT/pmc" 2 $FRAMES "$R/profiles/traffic_latest.json"
