@@ -120,5 +120,9 @@ static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 //   [8]     rounding + bias constant: 16384 + 128*256*SUM(w >> 8)   (pixels are fed as p-128)
 //   [9..11] padding
 constexpr int kCubicPackDwords = 12;
+// dwords per sub-pixel phase of the dot4-packed weight table of a KS x KS interpolation:
+// [KS*WIN signed high-byte dwords][KS*WIN unsigned low-byte dwords][bias][padding to 16 bytes],
+// WIN = 4-byte windows per stencil row (2 for Lanczos4, else 1).  Bilinear fills bytes 0-1 only.
+constexpr int pack_dwords(int ks) { return ks == 2 ? 8 : ks == 4 ? kCubicPackDwords : ks == 8 ? 36 : 0; }
 
 }  // namespace t360

@@ -55,7 +55,8 @@ struct TiledPlane {
 };
 struct TiledArgs {
   const int16_t* wtab;      // OpenCV Q15 table (direct tiles)
-  const uint32_t* wpack;    // kCubicPackDwords per phase (staged tiles)
+  const uint32_t* wpack;    // pack_dwords(ks) per phase (staged tiles)
+  int ks;                   // taps per axis of the interpolation: 1, 2, 4 (bicubic) or 8
   int nframes;
   int frames_per_block;
   int nplanes;

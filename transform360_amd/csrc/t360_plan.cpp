@@ -48,8 +48,12 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
                        hipStream_t stream, GatherPlan* plan) {
   plan->valid = false;
   plan->ntiles = 0;
-  if (ksize != 4) return true;  // only the bicubic kernel is tiled in this round
-  const int halo_lo = ksize / 2 - 1, halo_hi = ksize / 2;
+  if (!(ksize == 1 || ksize == 2 || ksize == 4 || ksize == 8)) return true;
+  // taps of a ksize-wide stencil around the LUT's integer coordinate: -(ksize/2-1) .. +ksize/2
+  // (nearest: the pixel itself)
+  const int halo_lo = ksize == 1 ? 0 : ksize / 2 - 1, halo_hi = ksize == 1 ? 0 : ksize / 2;
+  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane, 16x16 tiles only
+  const bool only16 = ksize == 8;
   int max_chunks = max_box_bytes / kStageChunk;
   if (max_chunks > 256 * kStageChunksPerLane) max_chunks = 256 * kStageChunksPerLane;
   const int regions_x = (dw + 127) / 128, regions_y = (dh + 31) / 32;
@@ -118,11 +122,12 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
       // option A: four 128x8 strips (wide row fragments stream ~2x faster from HBM than the
       // ~100-byte fragments of 32x32 tiles); option B: four 32x32 tiles with 16x16 fallback.
       Box strip[4], tile[4];
-      bool strips_ok = allow_strips;
+      bool strips_ok = allow_strips && !only16;
       int64_t strip_bytes = 0, tile_bytes = 0;
       for (int k = 0; k < 4; k++) {
         strip[k] = make_box(b + 6 * k, halo_lo, halo_hi, max_chunks);
         tile[k] = make_box(b + 6 * (4 + k), halo_lo, halo_hi, max_chunks);
+        if (only16) tile[k].fits = false;
         if (!strip[k].empty) {
           strips_ok = strips_ok && strip[k].fits;
           strip_bytes += (int64_t)strip[k].cpr * kStageChunk * strip[k].rows;
@@ -193,29 +198,37 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   return true;
 }
 
-// Re-pack OpenCV's Q15 bicubic table for v_dot4 (layout: t360_internal.h kCubicPackDwords)
-void pack_cubic_weights(const std::vector<int16_t>& tab, std::vector<uint32_t>* out) {
+// Re-pack OpenCV's Q15 table of a ks x ks interpolation for v_dot4 (layout: t360_internal.h pack_dwords):
+// window (r, w) holds taps 4w .. 4w+3 of stencil row r; bilinear's two taps sit in bytes 0-1.
+void pack_weights(const std::vector<int16_t>& tab, int ks, std::vector<uint32_t>* out) {
   const int phases = kInterTabSize * kInterTabSize;
-  out->assign((size_t)phases * kCubicPackDwords, 0);
+  const int stride = pack_dwords(ks);
+  const int win = ks == 8 ? 2 : 1, nw = ks * win;
+  out->assign((size_t)phases * stride, 0);
   for (int f = 0; f < phases; f++) {
-    const int16_t* w = &tab[(size_t)f * 16];
-    uint32_t* o = &(*out)[(size_t)f * kCubicPackDwords];
+    const int16_t* w = &tab[(size_t)f * ks * ks];
+    uint32_t* o = &(*out)[(size_t)f * stride];
     int sum_hi = 0;
-    for (int r = 0; r < 4; r++) {
-      uint32_t hi = 0, lo = 0;
-      for (int c = 0; c < 4; c++) {
-        const int v = w[r * 4 + c];
-        const int h = v >> 8;   // arithmetic shift: floor, in [-128, 127]
-        const int l = v & 255;  // v == h * 256 + l
-        sum_hi += h;
-        hi |= (uint32_t)(h & 255) << (8 * c);
-        lo |= (uint32_t)l << (8 * c);
+    for (int r = 0; r < ks; r++)
+      for (int q = 0; q < win; q++) {
+        uint32_t hi = 0, lo = 0;
+        for (int c = 0; c < 4; c++) {
+          const int tap = 4 * q + c;
+          if (tap >= ks) break;
+          const int v = w[r * ks + tap];
+          const int h = v >> 8;   // arithmetic shift: floor, in [-128, 127]
+          const int l = v & 255;  // v == h * 256 + l
+          sum_hi += h;
+          hi |= (uint32_t)(h & 255) << (8 * c);
+          lo |= (uint32_t)l << (8 * c);
+        }
+        o[r * win + q] = hi;
+        o[nw + r * win + q] = lo;
       }
-      o[r] = hi;
-      o[4 + r] = lo;
-    }
-    o[8] = (uint32_t)((1 << (kCoefBits - 1)) + 128 * 256 * sum_hi);
+    o[2 * nw] = (uint32_t)((1 << (kCoefBits - 1)) + 128 * 256 * sum_hi);
   }
 }
+
+void pack_cubic_weights(const std::vector<int16_t>& tab, std::vector<uint32_t>* out) { pack_weights(tab, 4, out); }
 
 }  // namespace t360

@@ -26,5 +26,6 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
                        hipStream_t stream, GatherPlan* plan);
 
 void pack_cubic_weights(const std::vector<int16_t>& q15_table, std::vector<uint32_t>* out);
+void pack_weights(const std::vector<int16_t>& q15_table, int ks, std::vector<uint32_t>* out);
 
 }  // namespace t360

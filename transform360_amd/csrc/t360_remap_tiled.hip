@@ -39,18 +39,31 @@ constexpr int kRingMaxSlots = 8;
 __device__ __forceinline__ uint32_t bias128(uint32_t px4) { return px4 ^ 0x80808080u; }
 
 // ---- per-pixel geometry shared by both staging variants --------------------------------------
-template <int NPX>
-struct PixelSetup {
-  int off[NPX];         // byte offset of the stencil's top-left tap inside the staged box
-  uint32_t wh[NPX][4];  // signed high bytes of the 4x4 weights, one dword per stencil row
-  uint32_t wl[NPX][4];  // unsigned low bytes
-  int bias[NPX];        // 16384 + 128*256*SUM(wh)
-  bool live[NPX];       // pixel inside the plane (partial tiles)
+// KS = taps per axis: 1 nearest, 2 bilinear, 4 bicubic, 8 Lanczos4.  A stencil row is read as
+// WIN 4-byte windows (bilinear uses the first two bytes of its window; the packed weights of the
+// other two are zero).
+template <int KS>
+struct Stencil {
+  static constexpr int ROWS = KS;
+  static constexpr int WIN = KS == 8 ? 2 : 1;
+  static constexpr int NW = KS == 1 ? 0 : ROWS * WIN;  // weight dwords per half (hi / lo)
+  static constexpr int PACK = pack_dwords(KS);         // dwords per phase in the packed table
 };
 
-template <int NPX>
+template <int NPX, int KS>
+struct PixelSetup {
+  static constexpr int NWA = Stencil<KS>::NW > 0 ? Stencil<KS>::NW : 1;
+  int off[NPX];           // byte offset of the stencil's top-left tap inside the staged box
+  uint32_t wh[NPX][NWA];  // signed high bytes of the weights, one dword per 4-byte window
+  uint32_t wl[NPX][NWA];  // unsigned low bytes
+  int bias[NPX];          // 16384 + 128*256*SUM(wh)
+  bool live[NPX];         // pixel inside the plane (partial tiles)
+};
+
+template <int NPX, int KS>
 __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t* __restrict__ wpack,
-                                            const TileDesc& t, int pitch, PixelSetup<NPX>& s, int debug = 0) {
+                                            const TileDesc& t, int pitch, PixelSetup<NPX, KS>& s, int debug = 0) {
+  constexpr int NW = Stencil<KS>::NW;
   const int tid = threadIdx.x;
   uint32_t words[4];
   if (NPX == 4) {
@@ -65,74 +78,105 @@ __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t
     s.live[p] = (e >> 31) == 0;
     const int rx = e & 1023, ry = (e >> 10) & 255, frac = (debug & 128) ? 0 : (e >> 18) & 1023;
     s.off[p] = s.live[p] ? ry * pitch + rx : 0;
-    const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(wpack + (size_t)frac * kCubicPackDwords);
-    const uint4 h = wp[0], l = wp[1];
-    s.wh[p][0] = h.x; s.wh[p][1] = h.y; s.wh[p][2] = h.z; s.wh[p][3] = h.w;
-    s.wl[p][0] = l.x; s.wl[p][1] = l.y; s.wl[p][2] = l.z; s.wl[p][3] = l.w;
-    // rounding + bias term 16384 + 128*256*SUM(wh): SUM of the 16 signed high bytes by dot4 with ones
-    int sh = 0;
+    s.bias[p] = 0;
+    if (NW > 0) {
+      // [NW high dwords][NW low dwords], 16-byte aligned: 2*NW/4 vector loads
+      const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(wpack + (size_t)frac * Stencil<KS>::PACK);
+      uint32_t w[2 * (NW > 0 ? NW : 2)];
 #pragma unroll
-    for (int r = 0; r < 4; r++) sh = __builtin_amdgcn_sdot4((int)s.wh[p][r], 0x01010101, sh, false);
-    s.bias[p] = (1 << (kCoefBits - 1)) + 128 * 256 * sh;
+      for (int k = 0; k < (2 * NW) / 4; k++) {
+        const uint4 v = wp[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+      }
+      // rounding + bias term 16384 + 128*256*SUM(wh): SUM of the signed high bytes by dot4 with ones
+      int sh = 0;
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        s.wh[p][k] = w[k];
+        s.wl[p][k] = w[NW + k];
+        sh = __builtin_amdgcn_sdot4((int)w[k], 0x01010101, sh, false);
+      }
+      s.bias[p] = (1 << (kCoefBits - 1)) + 128 * 256 * sh;
+    }
   }
 }
 
 // Make hipcc wait for its own (counted) loads HERE: every loaded value passes through an empty
 // asm, so the compiler-inserted s_waitcnt lands before it and not in front of the first use
 // inside the frame loop, where it would also drain the DMA ring.
-template <int NPX>
-__device__ __forceinline__ void pin_pixels(PixelSetup<NPX>& s) {
+template <int NPX, int KS>
+__device__ __forceinline__ void pin_pixels(PixelSetup<NPX, KS>& s) {
 #pragma unroll
   for (int p = 0; p < NPX; p++) {
     asm volatile("" : "+v"(s.off[p]), "+v"(s.bias[p]));
 #pragma unroll
-    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(s.wh[p][r]), "+v"(s.wl[p][r]));
+    for (int r = 0; r < Stencil<KS>::NW; r++) asm volatile("" : "+v"(s.wh[p][r]), "+v"(s.wl[p][r]));
   }
 }
 
 // one frame of one tile: gather from the staged box at `box`, write the output pixels.
 // GROUP = pixels whose LDS reads are in flight together: 4 -> one LDS round trip per frame and
-// 32 VGPRs of read data; 2 -> two round trips, 16 VGPRs (fits 6 waves per SIMD).
+// 32 VGPRs of read data (bicubic); 2 -> two round trips, 16 VGPRs (fits 6 waves per SIMD).
 // (Unaligned ds_read_b32 windows were measured 2.8x SLOWER than aligned ds_read2_b32 + v_alignbit
-// on gfx950, so the window is always assembled from two aligned dwords.)
-template <int NPX, int GROUP>
-__device__ __forceinline__ void gather_store(const PixelSetup<NPX>& s, const uint8_t* __restrict__ box, int pitch,
+// on gfx950, so a window is always assembled from two aligned dwords.)
+template <int NPX, int KS, int GROUP>
+__device__ __forceinline__ void gather_store(const PixelSetup<NPX, KS>& s, const uint8_t* __restrict__ box, int pitch,
                                              uint8_t* __restrict__ d, int dstride, bool dword_store) {
   constexpr int G = GROUP < NPX ? GROUP : NPX;
+  constexpr int ROWS = Stencil<KS>::ROWS, WIN = Stencil<KS>::WIN;
   int v[NPX];
+  if (KS == 1) {
+    // nearest: the byte itself (cv::remap INTER_NEAREST)
 #pragma unroll
-  for (int p0 = 0; p0 < NPX; p0 += G) {
-    // Phase 1: the group's LDS reads in flight at once; phase 2: the dot products.
-    uint64_t win[G][4];
+    for (int p = 0; p < NPX; p++) v[p] = box[s.off[p]];
+  } else {
 #pragma unroll
-    for (int p = 0; p < G; p++) {
-      const int a4 = s.off[p0 + p] & ~3;
+    for (int p0 = 0; p0 < NPX; p0 += G) {
+      // Phase 1: the group's LDS reads in flight at once; phase 2: the dot products.
+      uint32_t win[G][ROWS][WIN + 1];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
-        win[p][r] = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+      for (int p = 0; p < G; p++) {
+        const int a4 = s.off[p0 + p] & ~3;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(box + a4 + r * pitch);
+#pragma unroll
+          for (int k = 0; k < WIN + 1; k++) win[p][r][k] = q[k];
+        }
       }
-    }
-    // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
+      // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
 #pragma unroll
-    for (int p = 0; p < G; p++) {
+      for (int p = 0; p < G; p++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) asm volatile("" : "+v"(win[p][r]));
-    }
+        for (int r = 0; r < ROWS; r++) {
+          if (WIN == 1) {
+            uint64_t pr = (uint64_t)win[p][r][0] | ((uint64_t)win[p][r][1] << 32);
+            asm volatile("" : "+v"(pr));
+            win[p][r][0] = (uint32_t)pr;
+            win[p][r][1] = (uint32_t)(pr >> 32);
+          } else {
 #pragma unroll
-    for (int p = 0; p < G; p++) {
-      const uint32_t sh = (uint32_t)(s.off[p0 + p] & 3) * 8u;
-      int hi = 0;
-      uint32_t lo = (uint32_t)s.bias[p0 + p];
+            for (int k = 0; k < WIN + 1; k++) asm volatile("" : "+v"(win[p][r][k]));
+          }
+        }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        // 4 consecutive source bytes out of the aligned 8-byte window
-        const uint32_t px4 = __builtin_amdgcn_alignbit((uint32_t)(win[p][r] >> 32), (uint32_t)win[p][r], sh);
-        hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[p0 + p][r], hi, false);
-        lo = __builtin_amdgcn_udot4(px4, s.wl[p0 + p][r], lo, false);
+      for (int p = 0; p < G; p++) {
+        const uint32_t sh = (uint32_t)(s.off[p0 + p] & 3) * 8u;
+        int hi = 0;
+        uint32_t lo = (uint32_t)s.bias[p0 + p];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+          for (int w = 0; w < WIN; w++) {
+            // 4 consecutive source bytes out of the aligned dword pair
+            const uint32_t px4 = __builtin_amdgcn_alignbit(win[p][r][w + 1], win[p][r][w], sh);
+            hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[p0 + p][r * WIN + w], hi, false);
+            lo = __builtin_amdgcn_udot4(px4, s.wl[p0 + p][r * WIN + w], lo, false);
+          }
+        }
+        const int sum = (hi << 8) + (int)lo;  // = SUM p*w + 16384
+        v[p0 + p] = sat_u8(sum >> kCoefBits);
       }
-      const int sum = (hi << 8) + (int)lo;  // = SUM p*w + 16384
-      v[p0 + p] = sat_u8(sum >> kCoefBits);
     }
   }
   if (NPX == 4) {
@@ -365,14 +409,14 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
   if (which == 0 && !(a.debug & (32 | 16))) trace_mark(a, 6);
 }
 
-template <int NPX, int GROUP>
+template <int NPX, int KS, int GROUP>
 __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
                                                const uint8_t* __restrict__ lds, int f0, int f1) {
   const RingGeom g = ring_geom(t, a.ring_bytes);
-  PixelSetup<NPX> px;
-  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px, a.debug);
+  PixelSetup<NPX, KS> px;
+  load_pixels<NPX, KS>(pl, a.wpack, t, g.pitch, px, a.debug);
   if (a.trace && !(a.debug & 16)) {
-    pin_pixels<NPX>(px);  // make the compiler wait for the loads before the timestamp
+    pin_pixels<NPX, KS>(px);  // make the compiler wait for the loads before the timestamp
     if (threadIdx.x < 64) trace_mark(a, 4);
   }
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
@@ -386,7 +430,7 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
     unsigned long long c0 = tracing ? wall_clock64() : 0;
     frame_barrier();
     unsigned long long c1 = tracing ? wall_clock64() : 0;
-    if (!(a.debug & 8)) gather_store<NPX, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
+    if (!(a.debug & 8)) gather_store<NPX, KS, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
     if (tracing) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       acc_bar += c1 - c0;
@@ -473,9 +517,9 @@ __device__ __forceinline__ void self_loading_waves(const TiledArgs& a, const Til
     for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
   if (lane == 0 && wave == 0) trace_mark(a, 2);
 
-  PixelSetup<NPX> px;
-  load_pixels<NPX>(pl, a.wpack, t, g.pitch, px, a.debug);
-  pin_pixels<NPX>(px);  // hipcc's wait for its own loads lands here (and drains the prologue DMA with it)
+  PixelSetup<NPX, 4> px;
+  load_pixels<NPX, 4>(pl, a.wpack, t, g.pitch, px, a.debug);
+  pin_pixels<NPX, 4>(px);  // hipcc's wait for its own loads lands here (and drains the prologue DMA with it)
   if (lane == 0 && wave == 0) trace_mark(a, 4);
 
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
@@ -489,7 +533,7 @@ __device__ __forceinline__ void self_loading_waves(const TiledArgs& a, const Til
     if (!(a.debug & 1024)) frame_barrier();  // frame i is complete in LDS; everyone has left frame i-1's slot
     if (i + K - 1 < nf && !(a.debug & 4)) issue(f0 + i + K - 1, fill);
     fill = fill + 1 == K ? 0 : fill + 1;
-    if (!(a.debug & 8)) gather_store<NPX, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
+    if (!(a.debug & 8)) gather_store<NPX, 4, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
     d += pl.dst_frame_bytes;
     box += g.slot_bytes;
     if (box == ring_end) box = lds;
@@ -534,8 +578,9 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_self_kernel(TiledArgs a
 
 // VARIANT bit 0: LDS reads in groups of 2 pixels instead of 4 (fewer registers);
 //         bit 1: cap registers for 6 waves per SIMD (4 workgroups of 5 waves per CU)
-template <int VARIANT>
-__global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_cubic_dma_kernel(TiledArgs a) {
+//         KS: taps per axis of the interpolation (1, 2, 4, 8)
+template <int VARIANT, int KS>
+__global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_dma_kernel(TiledArgs a) {
   constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
   int b = xcd_contiguous(blockIdx.x, a.total_tiles);
@@ -567,10 +612,10 @@ __global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_cubic_
   }
   if (wave >= kLoaderWave) {
     loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
-  } else if (t.kind == kTileStaged16) {
-    consumer_waves<1, GROUP>(a, pl, t, lds, f0, f1);
+  } else if (KS == 8 || t.kind == kTileStaged16) {
+    consumer_waves<1, KS, GROUP>(a, pl, t, lds, f0, f1);  // Lanczos4 is planned as 16x16 tiles only (32 weight VGPRs per pixel)
   } else {
-    consumer_waves<4, GROUP>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
+    consumer_waves<(KS == 8 ? 1 : 4), KS, GROUP>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
   }
 }
 
@@ -638,9 +683,9 @@ __global__ __launch_bounds__(512, 1) void remap_tiled_cubic_persist_kernel(Tiled
     if (wave >= kLoaderWave) {
       loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
     } else if (t.kind == kTileStaged16) {
-      consumer_waves<1, GROUP>(a, pl, t, lds, f0, f1);
+      consumer_waves<1, 4, GROUP>(a, pl, t, lds, f0, f1);
     } else {
-      consumer_waves<4, GROUP>(a, pl, t, lds, f0, f1);
+      consumer_waves<4, 4, GROUP>(a, pl, t, lds, f0, f1);
     }
   }
 }
@@ -666,8 +711,8 @@ __device__ __forceinline__ void staged_tile_regs(const TiledArgs& a, const Tiled
                                                  uint8_t* __restrict__ lds, int f0, int f1) {
   const int tid = threadIdx.x;
   const int pitch = (int)t.cpr * kStageChunk;
-  PixelSetup<NPX> px;
-  load_pixels<NPX>(pl, a.wpack, t, pitch, px);
+  PixelSetup<NPX, 4> px;
+  load_pixels<NPX, 4>(pl, a.wpack, t, pitch, px);
 
   const int nch = (int)t.cpr * (int)t.rows;
   int goff[kStageChunksPerLane];  // fast chunk: byte offset inside the plane; slow: (row << 16) | col chunk
@@ -721,7 +766,7 @@ __device__ __forceinline__ void staged_tile_regs(const TiledArgs& a, const Tiled
   __syncthreads();
   for (int f = f0; f < f1; f++) {
     if (f + 1 < f1) fetch(f + 1);  // in flight while this frame is computed
-    gather_store<NPX, 4>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, pl.dstride, dword_store);
+    gather_store<NPX, 4, 4>(px, lds, pitch, pl.dst + (size_t)f * pl.dst_frame_bytes + dpos, pl.dstride, dword_store);
     __syncthreads();  // everyone is done reading this frame's box
     if (f + 1 < f1) {
       commit();
@@ -746,7 +791,8 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_regs_kernel(TiledArgs a
 // The few 16x16 tiles around each pole whose source box exceeds the staging budget (they span a
 // full quadrant of longitudes): one workgroup per (tile, frame), one pixel per
 // lane, 16 independent byte loads in flight per lane.
-__global__ __launch_bounds__(256) void remap_direct_cubic_kernel(TiledArgs a) {
+template <int KS>
+__global__ __launch_bounds__(256) void remap_direct_kernel(TiledArgs a) {
   int b = blockIdx.x;
   TiledPlane pl = a.plane[0];
   if (a.nplanes > 1 && b >= pl.ndirect) {
@@ -767,7 +813,7 @@ __global__ __launch_bounds__(256) void remap_direct_cubic_kernel(TiledArgs a) {
   if (ox >= pl.dw || oy >= pl.dh) return;
   const int f = blockIdx.y;
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
-  const int v = sample<4, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
+  const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
   pl.dst[(size_t)f * pl.dst_frame_bytes + (size_t)oy * pl.dstride + ox] = (uint8_t)v;
 }
 
@@ -777,20 +823,26 @@ hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream) {
   int total = 0;
   for (int k = 0; k < a.nplanes; k++) total += a.plane[k].ndirect;
   if (total <= 0 || a.nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(remap_direct_cubic_kernel, dim3(total, a.nframes, 1), dim3(256), 0, stream, a);
+  const dim3 grid(total, a.nframes, 1);
+  switch (a.ks) {
+    case 1: hipLaunchKernelGGL(remap_direct_kernel<1>, grid, dim3(256), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(remap_direct_kernel<2>, grid, dim3(256), 0, stream, a); break;
+    case 8: hipLaunchKernelGGL(remap_direct_kernel<8>, grid, dim3(256), 0, stream, a); break;
+    default: hipLaunchKernelGGL(remap_direct_kernel<4>, grid, dim3(256), 0, stream, a); break;
+  }
   return hipGetLastError();
 }
 
-template <int VARIANT>
+template <int VARIANT, int KS>
 static hipError_t launch_dma_variant(const TiledArgs& a, int groups, int nload, hipStream_t stream) {
   static int configured_lds = 0;
   if (a.ring_bytes > 64 * 1024 && configured_lds < a.ring_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_dma_kernel<VARIANT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_dma_kernel<VARIANT, KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
     if (e != hipSuccess) return e;
     configured_lds = a.ring_bytes;
   }
-  hipLaunchKernelGGL(remap_tiled_cubic_dma_kernel<VARIANT>, dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload),
+  hipLaunchKernelGGL((remap_tiled_dma_kernel<VARIANT, KS>), dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload),
                      (size_t)a.ring_bytes, stream, a);
   return hipGetLastError();
 }
@@ -799,7 +851,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
   if (a.total_tiles <= 0 || a.nframes <= 0) return hipSuccess;
   const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
   const int nload = a.loader_waves < 1 ? 1 : (a.loader_waves > 4 ? 4 : a.loader_waves);
-  if (a.variant & 4) {
+  if ((a.variant & 4) && a.ks == 4) {
     static int configured_self = 0;
     if (a.ring_bytes > 64 * 1024 && configured_self < a.ring_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_self_kernel<0>),
@@ -818,7 +870,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
                          stream, a);
     return hipGetLastError();
   }
-  if (a.variant & 8) {
+  if ((a.variant & 8) && a.ks == 4) {
     // persistent workgroups: a.work_counters (8 ints) must be zero at launch
     if (!a.work_counters || a.persist_slots <= 0) return hipErrorInvalidValue;
     static int configured_persist = 0;
@@ -841,11 +893,14 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
       hipLaunchKernelGGL(remap_tiled_cubic_persist_kernel<0>, dim3(grid), dim3(256 + 64 * nload), (size_t)a.ring_bytes, stream, p);
     return hipGetLastError();
   }
+  if (a.ks == 1) return launch_dma_variant<1, 1>(a, groups, nload, stream);
+  if (a.ks == 2) return launch_dma_variant<1, 2>(a, groups, nload, stream);
+  if (a.ks == 8) return launch_dma_variant<1, 8>(a, groups, nload, stream);
   switch (a.variant & 3) {
-    case 0: return launch_dma_variant<0>(a, groups, nload, stream);
-    case 1: return launch_dma_variant<1>(a, groups, nload, stream);
-    case 2: return launch_dma_variant<2>(a, groups, nload, stream);
-    default: return launch_dma_variant<3>(a, groups, nload, stream);
+    case 0: return launch_dma_variant<0, 4>(a, groups, nload, stream);
+    case 1: return launch_dma_variant<1, 4>(a, groups, nload, stream);
+    case 2: return launch_dma_variant<2, 4>(a, groups, nload, stream);
+    default: return launch_dma_variant<3, 4>(a, groups, nload, stream);
   }
 }
 

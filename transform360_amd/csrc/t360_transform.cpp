@@ -253,9 +253,9 @@ bool VideoFrameTransform::ensureWeights() {
   if (!check(hipMemcpy(weights_.as<void>(), tab.data(), tab.size() * sizeof(int16_t), hipMemcpyHostToDevice),
              "hipMemcpy(weights)"))
     return false;
-  if (interp == CUBIC) {
+  {
     std::vector<uint32_t> pack;
-    pack_cubic_weights(tab, &pack);
+    pack_weights(tab, ks, &pack);
     if (!weights_pack_.reserve(pack.size() * sizeof(uint32_t))) return check(hipErrorOutOfMemory, "hipMalloc(weights)");
     if (!check(hipMemcpy(weights_pack_.as<void>(), pack.data(), pack.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
                "hipMemcpy(weights)"))
@@ -438,8 +438,10 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     // tile work list of the LDS-tiled gather (bicubic + BORDER_WRAP only in this round)
     const bool barrel = olay == LAYOUT_BARREL || olay == LAYOUT_BARREL_SPLIT;
     p.plan.valid = false;
-    if (P.interp == CUBIC && !barrel && !getenv("T360_NO_TILED")) {
-      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, 4,
+    const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
+    const bool tile_it = ks == 4 || (ks != 0 && !getenv("T360_TILED_CUBIC_ONLY"));
+    if (tile_it && !barrel && !getenv("T360_NO_TILED")) {
+      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, ks,
                              ((ring_bytes_ / 2 - 64) / 1024) * 1024,  // a ring slot = whole KiB pieces + 64
                              stream_, &p.plan))
         return check(hipErrorUnknown, "gather plan");
@@ -875,6 +877,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   fused.ring_bytes = ring_bytes_;
   fused.loader_waves = loader_waves_;
   fused.variant = dma_variant_;
+  fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
   fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
   const bool multi = n_frames > 1;
   TiledArgs direct = fused;  // the pole tiles too large to stage, all planes in one small launch
@@ -887,7 +890,11 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
                  "fill launch"))
         return false;
     }
-    if (p.plan.valid && interp == CUBIC && !barrel && j.in_w == p.in_w && j.in_h == p.in_h) {
+    // chunks go global -> LDS by DMA only from 16-byte friendly buffers; the register-staged
+    // fallback exists for bicubic only, other interpolations then use the general gather
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
+                        (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
+    if (p.plan.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && (interp == CUBIC || (vec_ok && use_dma_))) {
       TiledPlane tp;
       memset(&tp, 0, sizeof(tp));
       tp.src = s.ptr;
@@ -906,8 +913,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       tp.ntiles = p.plan.ntiles;
       tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
                         (!multi || (j.out_frame_bytes & 3) == 0);
-      tp.src_vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
-                      (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
+      tp.src_vec_ok = vec_ok;
       tp.ndirect = p.plan.ndirect;
       if (tp.ndirect > 0 && direct.nplanes < 4) direct.plane[direct.nplanes++] = tp;
       if (tp.src_vec_ok && use_dma_ && fused.nplanes < 4) {
