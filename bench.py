@@ -253,8 +253,10 @@ def main():
             "fps": round(fps, 1),
             "frac_of_hbm_roofline_whole_job": round(alg_frame * fps / (HBM_PEAK_BPS * world), 4),
             "roofline": {
-                "bound": "hbm", "kernel": "remap_tiled_cubic_dma_kernel: Y+U+V planes of %d frames per launch" % F
-                          if args.config in (2, 3) else "remap_gather_kernel launches of one step (Y, U, V planes of %d frames)" % F,
+                "bound": "hbm",
+                "kernel": "remap_tiled_dma_kernel<1,%d>: Y+U+V planes of %d frames per launch%s" % (
+                    {0: 1, 1: 2, 2: 4, 4: 8}.get(int(ctx.interpolation_alg), 4), F,
+                    " (+ the low-pass launches of the step)" if ctx.enable_low_pass_filter else ""),
                 "achieved": round(luma_alg / luma_avg_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                 "frac": round(luma_alg / luma_avg_s / HBM_PEAK_BPS, 4),
                 "algorithmic_bytes_per_launch": luma_alg, "avg_launch_ms": round(luma_avg_s * 1e3, 4),
@@ -263,6 +265,24 @@ def main():
             "init_ms": round(init_ms, 1),
             "output_checksums": checksums,
         }
+        if world == 1:
+            # "achievable" HBM rate of this box for reference: a plain device-to-device copy (read + write)
+            try:
+                n = 1 << 30
+                a_ = torch.empty(n, dtype=torch.uint8, device="cuda")
+                b_ = torch.empty(n, dtype=torch.uint8, device="cuda")
+                b_.copy_(a_)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(5):
+                    b_.copy_(a_)
+                ev1.record()
+                torch.cuda.synchronize()
+                res["hbm_copy_GBps_measured"] = round(5 * 2 * n / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+                del a_, b_
+            except RuntimeError:
+                pass
+        res["Mpix_s_in"] = round(fps * in_w * in_h / 1e6, 1)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)
         print(json.dumps(res))

@@ -175,6 +175,13 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     return;
   }
   stream_ = own_stream_;
+  for (int k = 0; k < 3; k++)
+    if (hipStreamCreateWithFlags(&lp_streams_[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&lp_join_[k], hipEventDisableTiming) != hipSuccess) {
+      printf("transform360: cannot create the low-pass streams\n");
+      return;
+    }
+  if (hipEventCreateWithFlags(&lp_fork_, hipEventDisableTiming) != hipSuccess) return;
   if (hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&fork_event_, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&join_event_, hipEventDisableTiming) != hipSuccess) {
@@ -206,6 +213,14 @@ VideoFrameTransform::~VideoFrameTransform() {
     (void)hipStreamSynchronize(aux_stream_);
     (void)hipStreamDestroy(aux_stream_);
   }
+  for (int k = 0; k < 3; k++) {
+    if (lp_streams_[k]) {
+      (void)hipStreamSynchronize(lp_streams_[k]);
+      (void)hipStreamDestroy(lp_streams_[k]);
+    }
+    if (lp_join_[k]) (void)hipEventDestroy(lp_join_[k]);
+  }
+  if (lp_fork_) (void)hipEventDestroy(lp_fork_);
   if (fork_event_) (void)hipEventDestroy(fork_event_);
   if (join_event_) (void)hipEventDestroy(join_event_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -708,13 +723,14 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
 
 bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes,
                                      int in_stride, uint8_t* d_out, int64_t out_frame_bytes,
-                                     int out_stride, int w, int h, int n_frames, int imagePlaneIndex) {
+                                     int out_stride, int w, int h, int n_frames, int imagePlaneIndex,
+                                     hipStream_t stream) {
   if (!ensureTiles(p, w, h, imagePlaneIndex)) return false;
   if (!p.full_cover) {
     // Mat::zeros(...) of filterPlane (:625): only visible where no segment writes
     for (int f = 0; f < n_frames; f++)
       if (!check(hipMemset2DAsync(d_out + (size_t)f * out_frame_bytes, (size_t)out_stride, 0, (size_t)w,
-                                  (size_t)h, stream_), "hipMemset2DAsync"))
+                                  (size_t)h, stream), "hipMemset2DAsync"))
         return false;
   }
   LowpassArgs a;
@@ -750,7 +766,7 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
     a.ntiles = p.ntiles;
     a.max_rows = p.max_rows;
   }
-  return check(launch_lowpass(a, n_frames, stream_), "low-pass launch");
+  return check(launch_lowpass(a, n_frames, stream), "low-pass launch");
 }
 
 // transformPlane's needResize branch (VideoFrameTransform.cpp:759-776): gather into a warp-map-sized
@@ -853,13 +869,24 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       total += (size_t)bstride * jobs[k].in_h * (size_t)n_frames;
     }
     if (!blurred_.reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
+    const bool side = njobs > 1 && njobs <= 4;  // planes 1.. on their own streams beside plane 0
+    if (side && !check(hipEventRecord(lp_fork_, stream_), "hipEventRecord")) return false;
     for (int k = 0; k < njobs; k++) {
       const PlaneJob& j = jobs[k];
       const int bstride = (j.in_w + 255) & ~255;
       const int64_t plane_bytes = (int64_t)bstride * j.in_h;
       uint8_t* bl = blurred_.as<uint8_t>() + offs[(size_t)k];
+      hipStream_t st = stream_;
+      if (side && k > 0) {
+        st = lp_streams_[k - 1];
+        if (!check(hipStreamWaitEvent(st, lp_fork_, 0), "hipStreamWaitEvent")) return false;
+      }
       if (!runLowpass(planes_[j.idx], j.in, j.in_frame_bytes, j.in_stride, bl, plane_bytes, bstride, j.in_w, j.in_h,
-                      n_frames, j.image_plane))
+                      n_frames, j.image_plane, st))
+        return false;
+      if (side && k > 0 &&
+          (!check(hipEventRecord(lp_join_[k - 1], st), "hipEventRecord") ||
+           !check(hipStreamWaitEvent(stream_, lp_join_[k - 1], 0), "hipStreamWaitEvent")))
         return false;
       srcs[(size_t)k] = Src{bl, plane_bytes, bstride};
     }
@@ -1092,7 +1119,7 @@ bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int w
     return false;
   }
   DeviceGuard g(device_);
-  return runLowpass(planes_[idx], d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx);
+  return runLowpass(planes_[idx], d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx, stream_);
 }
 
 bool VideoFrameTransform::getMapSize(int idx, int* w, int* h) const {

@@ -108,7 +108,7 @@ class VideoFrameTransform {
   bool buildResizePlan(PlaneState& p);
   bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
-                  int imagePlaneIndex);
+                  int imagePlaneIndex, hipStream_t stream);
 
   FrameTransformContext ctx_;
   bool ok_ = false;
@@ -117,6 +117,9 @@ class VideoFrameTransform {
   hipStream_t stream_ = nullptr;
   hipStream_t aux_stream_ = nullptr;  // direct (unstaged) pole tiles run here beside the main gather
   hipEvent_t fork_event_ = nullptr, join_event_ = nullptr;
+  // the low-pass launches of planes 1.. of a batch run beside plane 0's (independent planes, small grids)
+  hipStream_t lp_streams_[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t lp_fork_ = nullptr, lp_join_[3] = {nullptr, nullptr, nullptr};
   PlaneState planes_[t360::kMaxMaps];
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
