@@ -2,7 +2,7 @@
 // of the reference's supersample antialiasing (transformPlane's needResize branch,
 // VideoFrameTransform.cpp:759-776: remap into a warp-map-sized image, then resize to the output).
 //
-// Arithmetic of OpenCV 4.x resize.cpp (restated CPU-side in oracle/t360_oracle_cv.c):
+// Arithmetic of OpenCV 4.x resize.cpp (DESIGN.md section 2 lists what is pinned):
 //   integer factors (source = factor x destination exactly), "ResizeAreaFast":
 //       2 x 2      (a + b + c + d + 2) >> 2
 //       otherwise  sat_u8(rint((float)int_sum * (1.f / area)))
