@@ -19,7 +19,9 @@
  * What is different behind the boundary: maps, low-pass filtering and the gather
  * run as HIP kernels on an MI355X.  inputData / outputData may be host pointers
  * (staged over PCIe, synchronous like the reference) or device pointers (used in
- * place, see Transform360/t360_device.h for the stream / batch additions).
+ * place; the call first waits for work already queued on the device unless the caller
+ * took over ordering with T360_setStream -- see Transform360/t360_device.h for the
+ * stream / batch additions).
  */
 #ifndef TRANSFORM360_VIDEOFRAMETRANSFORMHANDLER_H
 #define TRANSFORM360_VIDEOFRAMETRANSFORMHANDLER_H

@@ -34,6 +34,13 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def _ready():
+    """Tensors are created on torch's stream, the handle works on its own non-blocking stream: the
+    reference ABI takes buffers that are READY (include/Transform360/VideoFrameTransformHandler.h)."""
+    import torch
+    torch.cuda.synchronize()
+
+
 def padded_cuda(h, w, pad, fill):
     import torch
     full = torch.full((h, w + pad), fill, dtype=torch.uint8, device="cuda")
@@ -74,6 +81,7 @@ def test_unsupported_request_is_refused_not_faked(T):
         ok = t.generateMapForPlane(1024, 512, 384, 256, 0)
         src = dev(np.zeros((512, 1024), np.uint8))
         dst = dev(np.zeros((256, 384), np.uint8))
+        _ready()
         assert not (ok and t.transformFramePlane(src, dst, 0))
     from transform360_amd.abi import LAYOUT_N
     with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_N)) as t:
@@ -121,11 +129,13 @@ def test_frame_case_device_pointers(name, T, oracle_mod, golden):
         if ctx.enable_low_pass_filter:
             import torch
             blur = torch.zeros((in_h, in_w), dtype=torch.uint8, device="cuda")
+            _ready()
             assert t.filterPlane(dsrc, blur, 0) and t.synchronize()
             wantb = o.filterPlane(src, 0)
             gotb = blur.cpu().numpy()
             assert np.array_equal(gotb, wantb), "low-pass stage: %d px differ, max |d| %d" % (
                 (gotb != wantb).sum(), np.abs(gotb.astype(int) - wantb.astype(int)).max())
+        _ready()
         assert t.transformFramePlane(dsrc, ddst, 0, 0)
     got = ddst.cpu().numpy()
     diff = np.abs(got.astype(int) - want.astype(int))
@@ -143,6 +153,7 @@ def test_frame_case_host_pointers(name, T, golden, oracle_mod):
     dst = full[:, :out_w]
     with T.VideoFrameTransform(cases.make_ctx(ov)) as t:
         assert t.generateMapForPlane(*dims, 0)
+        _ready()
         assert t.transformFramePlane(src, dst, 0, 0)     # numpy arrays = host pointers
     assert hx(oracle_mod.fnv1a64(np.ascontiguousarray(dst))) == golden["frames"][name]["out"]
     assert (full[:, out_w:] == 0xA5).all()
@@ -170,45 +181,71 @@ def test_filter_call_sequence_yuv420p(T, oracle_mod):
                 assert o.transformFramePlane(src, want, idx, plane)
                 full = np.full((oh, ow + 32), 0x11, np.uint8)
                 dst = full[:, :ow]
+                _ready()
                 assert t.transformFramePlane(src, dst, idx, plane)
                 assert np.array_equal(dst, want)
                 assert (full[:, ow:] == 0x11).all()
 
 
 # ---------------------------------------------------------------- batch entry point
-def test_batch_equals_per_plane_calls(T, oracle_mod):
+def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64):
+    """n frames x 3 planes through T360_transformFrames == per-plane oracle calls."""
     import torch
-    O = oracle_mod
-    in_w, in_h, out_w, out_h = 960, 480, 384, 256
-    for ov in (dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4)):
-        ctx = filter_defaults(**ov)
-        lin = T.FrameLayout(in_w, in_h, extra_pad=64)
-        lout = T.FrameLayout(out_w, out_h)
-        n = 5
-        d_in = torch.empty(n * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+    in_w, in_h, out_w, out_h = dims
+    ctx = filter_defaults(**ov)
+    lin = T.FrameLayout(in_w, in_h, extra_pad=extra_pad)
+    lout = T.FrameLayout(out_w, out_h)
+    d_in = torch.empty(n * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        T.fill_noise(d_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes], T.frame_seed(k))
+    d_out = torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    o = O.Oracle(ctx, threads=4)
+    with T.VideoFrameTransform(ctx) as t:
+        for idx, k in ((0, 0), (1, 1)):
+            d = (*lin.dims[k], *lout.dims[k])
+            assert t.generateMapForPlane(*d, idx) and o.generateMapForPlane(*d, idx)
+        assert t.setStream(torch.cuda.current_stream())
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
+        assert t.synchronize()
+        h_in = d_in.cpu().numpy()
+        h_out = d_out.cpu().numpy()
         for k in range(n):
-            T.fill_noise(d_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes], T.frame_seed(k))
-        d_out = torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        o = O.Oracle(ctx, threads=4)
-        with T.VideoFrameTransform(ctx) as t:
-            for idx, k in ((0, 0), (1, 1)):
-                d = (*lin.dims[k], *lout.dims[k])
-                assert t.generateMapForPlane(*d, idx) and o.generateMapForPlane(*d, idx)
-            assert t.setStream(torch.cuda.current_stream())
-            assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
-            assert t.synchronize()
-            h_in = d_in.cpu().numpy()
-            h_out = d_out.cpu().numpy()
-            for k in range(n):
-                fin = h_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes]
-                # the device generator and its host restatement agree byte for byte
-                assert np.array_equal(fin, T.noise_bytes(lin.frame_bytes, T.frame_seed(k)))
-                fout = h_out[k * lout.frame_bytes:(k + 1) * lout.frame_bytes]
-                for p in range(3):
-                    want = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
-                    assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
-                    assert np.array_equal(lout.plane_view(fout, p), want), (k, p)
+            fin = h_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes]
+            # the device generator and its host restatement agree byte for byte
+            assert np.array_equal(fin, T.noise_bytes(lin.frame_bytes, T.frame_seed(k)))
+            fout = h_out[k * lout.frame_bytes:(k + 1) * lout.frame_bytes]
+            for p in range(3):
+                want = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
+                assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
+                assert np.array_equal(lout.plane_view(fout, p), want), (k, p)
+
+
+def test_batch_equals_per_plane_calls(T, oracle_mod):
+    for ov in (dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4)):
+        _batch_case(T, oracle_mod, ov)
+
+
+@pytest.mark.parametrize("interp", [NEAREST, LINEAR, LANCZOS4])
+def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
+    # the LDS-tiled DMA-ring kernel instantiated for 1-, 2- and 8-tap stencils (frames 16-byte friendly)
+    _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0, interpolation_alg=interp), n=3, extra_pad=0)
+    # and the general gather for buffers that are not (odd padding)
+    _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0, interpolation_alg=interp), n=2, extra_pad=40)
+
+
+# every tuning / experiment switch of the tiled kernel must leave the pixels alone
+@pytest.mark.parametrize("env", [
+    {"T360_VARIANT": "0"}, {"T360_VARIANT": "4"}, {"T360_VARIANT": "5"}, {"T360_VARIANT": "9"},
+    {"T360_STRIPS": "1"}, {"T360_PAD": "0"}, {"T360_PAD": "2"}, {"T360_PAD": "3"}, {"T360_NO_DMA": "1"},
+    {"T360_LOADERS": "2"}, {"T360_FRAMES_PER_BLOCK": "2"}, {"T360_RING_KB": "24"}, {"T360_RING_KB": "80"},
+    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_kernel_variants_are_bit_identical(env, T, oracle_mod, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ov = dict(num_vertical_segments=5, num_horizontal_segments=4) if "LOWPASS" in "".join(env) else dict(enable_low_pass_filter=0)
+    _batch_case(T, oracle_mod, ov, n=5, extra_pad=0)
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)
@@ -225,6 +262,7 @@ def _full_size_case(T, O, ov, luma_dims, n_check_rows=None):
         assert t.generateMapForPlane(*luma_dims, 0)
         dsrc = dev(src)
         ddst = torch.zeros((out_h, out_w), dtype=torch.uint8, device="cuda")
+        _ready()
         assert t.transformFramePlane(dsrc, ddst, 0)
         got = ddst.cpu().numpy()
     diff = np.abs(got.astype(int) - want.astype(int))
@@ -259,6 +297,7 @@ def test_flat_plane_stays_flat(interp, T):
         assert t.generateMapForPlane(3840, 1920, 1536, 1024, 0)
         src = torch.full((1920, 3840), 173, dtype=torch.uint8, device="cuda")
         dst = torch.zeros((1024, 1536), dtype=torch.uint8, device="cuda")
+        _ready()
         assert t.transformFramePlane(src, dst, 0)
         assert (dst == 173).all().item()
 
@@ -273,6 +312,7 @@ def test_nearest_full_size_is_a_gather_of_the_map(T):
         T.fill_noise(src, 77)
         src = src.view(1920, 3840)
         dst = torch.zeros((1024, 1536), dtype=torch.uint8, device="cuda")
+        _ready()
         assert t.transformFramePlane(src, dst, 0)
         ix = torch.round(m[..., 0]).long() % 3840    # torch.round is round-half-even like cvRound
         iy = torch.round(m[..., 1]).long() % 1920
@@ -287,15 +327,19 @@ def test_error_convention(T, gpu_lib):
     with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
         src = dev(np.zeros((64, 128), np.uint8))
         dst = dev(np.zeros((32, 48), np.uint8))
+        _ready()
         assert not t.transformFramePlane(src, dst, 0)          # no map yet -> 0, no crash
         assert not t.generateMapForPlane(0, 64, 48, 32, 0)
         assert t.generateMapForPlane(128, 64, 48, 32, 0)
+        _ready()
         assert t.transformFramePlane(src, dst, 0)
+        _ready()
         assert not t.transformFramePlane(src, dst, 1)          # index 1 never generated
     # interpolation_alg = 3: the reference prints, writes nothing and still returns true (:780-783)
     with T.VideoFrameTransform(filter_defaults(interpolation_alg=3, enable_low_pass_filter=0)) as t:
         assert t.generateMapForPlane(128, 64, 48, 32, 0)
         dst = dev(np.full((32, 48), 9, np.uint8))
+        _ready()
         assert t.transformFramePlane(dev(np.zeros((64, 128), np.uint8)), dst, 0)
         assert (dst == 9).all().item()
 

@@ -1040,6 +1040,12 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   const size_t in_bytes = (size_t)inputWidthWithPadding * (size_t)(inputHeight - 1) + (size_t)inputWidth;
   const size_t out_bytes = (size_t)outputWidthWithPadding * (size_t)(outputHeight - 1) + (size_t)outputWidth;
 
+  if ((ik != PtrKind::Host || ok != PtrKind::Host) && stream_ == own_stream_) {
+    // device buffers usually come from work queued on the caller's streams, which this handle's
+    // private non-blocking stream does not order against: the call is synchronous anyway, so wait
+    // for the device first (callers that manage ordering themselves use T360_setStream)
+    if (!check(hipDeviceSynchronize(), "hipDeviceSynchronize")) return false;
+  }
   const uint8_t* d_in = inputData;
   int in_stride = inputWidthWithPadding;
   if (ik == PtrKind::Host) {
