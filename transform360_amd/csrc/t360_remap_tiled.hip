@@ -26,6 +26,8 @@
 //   * no MFMA: this is a gather, not a contraction.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "t360_internal.h"
 #include "t360_kernels.h"
 #include "t360_sample.h"
@@ -835,7 +837,7 @@ hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream) {
 
 template <int VARIANT, int KS>
 static hipError_t launch_dma_variant(const TiledArgs& a, int groups, int nload, hipStream_t stream) {
-  static int configured_lds = 0;
+  static std::atomic<int> configured_lds{0};  // handles on several host threads may launch concurrently
   if (a.ring_bytes > 64 * 1024 && configured_lds < a.ring_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_dma_kernel<VARIANT, KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
@@ -852,7 +854,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
   const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
   const int nload = a.loader_waves < 1 ? 1 : (a.loader_waves > 4 ? 4 : a.loader_waves);
   if ((a.variant & 4) && a.ks == 4) {
-    static int configured_self = 0;
+    static std::atomic<int> configured_self{0};
     if (a.ring_bytes > 64 * 1024 && configured_self < a.ring_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_self_kernel<0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
@@ -873,7 +875,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
   if ((a.variant & 8) && a.ks == 4) {
     // persistent workgroups: a.work_counters (8 ints) must be zero at launch
     if (!a.work_counters || a.persist_slots <= 0) return hipErrorInvalidValue;
-    static int configured_persist = 0;
+    static std::atomic<int> configured_persist{0};
     if (a.ring_bytes > 60 * 1024 && configured_persist < a.ring_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_cubic_persist_kernel<0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, a.ring_bytes);
