@@ -75,7 +75,8 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0;
   // 128x8 strips give ~330-byte row fragments (better for HBM) but measured ~4 % slower end to end
   // while the kernel is VALU-issue-bound; opt-in until that changes (DESIGN.md, round-1 notes)
-  const bool allow_strips = getenv("T360_STRIPS") != nullptr;
+  const int strips_mode = getenv("T360_STRIPS") ? atoi(getenv("T360_STRIPS")) : 0;  // 2: wherever a strip fits (experiment)
+  const bool allow_strips = strips_mode > 0;
   const int pad_mode = getenv("T360_PAD") ? atoi(getenv("T360_PAD")) : 1;
   int cpr_hist[64] = {0};
   auto emit = [&](const Box& bx, int kind, int tox, int toy, int ew, int eh) {
@@ -151,7 +152,7 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
         }
       }
       // strips win unless they stage clearly more bytes (curved rows on the polar faces)
-      if (strips_ok && strip_bytes * 2 <= tile_bytes * 3) {
+      if (strips_ok && (strip_bytes * 2 <= tile_bytes * 3 || strips_mode >= 2)) {
         for (int k = 0; k < 4; k++)
           if (!strip[k].empty) emit(strip[k], kTileStrip128, ox, oy + 8 * k, 128, 8);
         continue;
