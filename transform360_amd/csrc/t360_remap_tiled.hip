@@ -342,9 +342,38 @@ __device__ __forceinline__ RingGeom ring_geom(const TileDesc& t, int ring_bytes)
   return g;
 }
 
+// ---- flag synchronisation (VARIANT bit 4) -------------------------------------------------------
+// One s_barrier per frame makes every frame cost the SLOWEST of the four consumer waves (measured:
+// wave 0 spends 0.56 us gathering and 0.25 us waiting for its siblings, per frame).  With flags in
+// LDS the waves only meet through the ring: the loader publishes `ready` = frames landed, each
+// consumer wave publishes `done[w]` = frames it has finished reading, the loader refills a slot once
+// min(done) has passed it.  A fast wave may run up to K-1 frames ahead of a slow one.
+// ctrl[0] = ready, ctrl[4..7] = done[0..3]; LDS operations of one wave execute in order, so a flag
+// written after a wave's reads (or after the loader's vmcnt wait) is ordered behind them.
+__device__ __forceinline__ volatile uint32_t* ring_ctrl(const uint8_t* lds, int ring_bytes) {
+  return reinterpret_cast<volatile uint32_t*>(const_cast<uint8_t*>(lds) + ring_bytes);
+}
+__device__ __forceinline__ int poll_at_least(volatile uint32_t* flag, int want, int seen) {
+  while (seen < want) {
+    seen = __builtin_amdgcn_readfirstlane((int)*flag);
+    if (seen < want) __builtin_amdgcn_s_sleep(1);
+  }
+  return seen;
+}
+__device__ __forceinline__ int poll_min4_at_least(volatile uint32_t* flags, int want, int seen) {
+  while (seen < want) {
+    const uint32_t a0 = flags[0], a1 = flags[1], a2 = flags[2], a3 = flags[3];
+    seen = __builtin_amdgcn_readfirstlane((int)min(min(a0, a1), min(a2, a3)));
+    if (seen < want) __builtin_amdgcn_s_sleep(1);
+  }
+  return seen;
+}
+
 // `which` of `nloaders` loader waves: it owns the 1 KiB pieces j = which, which + nloaders, ...
+template <bool FLAGS>
 __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
-                                            uint32_t lds_base, int f0, int f1, int which, int nloaders) {
+                                            uint32_t lds_base, int f0, int f1, int which, int nloaders,
+                                            volatile uint32_t* ctrl = nullptr) {
   const int lane = threadIdx.x & 63;
   const RingGeom g = ring_geom(t, a.ring_bytes);
   const int nj_all = (g.nch + 63) >> 6;
@@ -383,6 +412,7 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
     for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
   if (which == 0) trace_mark(a, 2);
   int fill = (K - 1) % K;
+  int min_done = 0;
   unsigned long long acc_wait = 0, acc_bar = 0, acc_issue = 0;
   const bool tracing = a.trace != nullptr && (a.debug & 16);
   for (int i = 0; i < nf; i++) {
@@ -391,7 +421,13 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
     wait_vmcnt((a.debug & 4) ? 0 : min(K - 2, nf - 1 - i) * nj);
     unsigned long long c1 = tracing ? wall_clock64() : 0;
     if (i == 0 && which == 0 && !tracing) trace_mark(a, 3);
-    frame_barrier();  // frame i is visible to the consumers; they have left frame i-1's slot
+    if (FLAGS) {
+      if (lane == 0) ctrl[0] = (uint32_t)(i + 1);  // frame i has landed
+      // the slot frame i-1 used is refilled next: every consumer wave must have left it
+      if (i + K - 1 < nf) min_done = poll_min4_at_least(ctrl + 4, i, min_done);
+    } else {
+      frame_barrier();  // frame i is visible to the consumers; they have left frame i-1's slot
+    }
     unsigned long long c2 = tracing ? wall_clock64() : 0;
     if (i + K - 1 < nf && !(a.debug & 4)) issue(f0 + i + K - 1, fill);
     fill = fill + 1 == K ? 0 : fill + 1;
@@ -411,7 +447,7 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
   if (which == 0 && !(a.debug & (32 | 16))) trace_mark(a, 6);
 }
 
-template <int NPX, int KS, int GROUP>
+template <int NPX, int KS, int GROUP, bool FLAGS = false>
 __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
                                                const uint8_t* __restrict__ lds, int f0, int f1) {
   const RingGeom g = ring_geom(t, a.ring_bytes);
@@ -428,11 +464,22 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
   const int nf = f1 - f0;
   unsigned long long acc_bar = 0, acc_work = 0;
   const bool tracing = a.trace != nullptr && (a.debug & 16);
+  volatile uint32_t* const ctrl = ring_ctrl(lds, a.ring_bytes);
+  const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int ready = 0;
+  if (FLAGS) pin_pixels<NPX, KS>(px);  // hipcc's wait for its own loads: before the loop, not inside it
   for (int i = 0; i < nf; i++) {
     unsigned long long c0 = tracing ? wall_clock64() : 0;
-    frame_barrier();
+    if (FLAGS)
+      ready = poll_at_least(ctrl, i + 1, ready);  // frame i is complete in LDS
+    else
+      frame_barrier();
     unsigned long long c1 = tracing ? wall_clock64() : 0;
     if (!(a.debug & 8)) gather_store<NPX, KS, GROUP>(px, box, g.pitch, d, pl.dstride, dword_store);
+    if (FLAGS) {
+      asm volatile("" ::: "memory");
+      if ((threadIdx.x & 63) == 0) ctrl[4 + my_wave] = (uint32_t)(i + 1);  // behind this wave's reads of frame i
+    }
     if (tracing) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       acc_bar += c1 - c0;
@@ -612,12 +659,18 @@ __global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_dma_ke
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
   }
+  constexpr bool FLAGS = (VARIANT & 16) != 0;
+  if (FLAGS) {  // flag block behind the ring: ready = 0, done[] = 0
+    if (threadIdx.x < 8) ring_ctrl(lds, a.ring_bytes)[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   if (wave >= kLoaderWave) {
-    loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
+    loader_wave<FLAGS>(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave,
+                       ring_ctrl(lds, a.ring_bytes));
   } else if (KS == 8 || t.kind == kTileStaged16) {
-    consumer_waves<1, KS, GROUP>(a, pl, t, lds, f0, f1);  // Lanczos4 is planned as 16x16 tiles only (32 weight VGPRs per pixel)
+    consumer_waves<1, KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1);  // Lanczos4 is planned as 16x16 tiles only (32 weight VGPRs per pixel)
   } else {
-    consumer_waves<(KS == 8 ? 1 : 4), KS, GROUP>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
+    consumer_waves<(KS == 8 ? 1 : 4), KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
   }
 }
 
@@ -683,7 +736,7 @@ __global__ __launch_bounds__(512, 1) void remap_tiled_cubic_persist_kernel(Tiled
     const int f0 = g * a.frames_per_block;
     const int f1 = min(f0 + a.frames_per_block, a.nframes);
     if (wave >= kLoaderWave) {
-      loader_wave(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
+      loader_wave<false>(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave);
     } else if (t.kind == kTileStaged16) {
       consumer_waves<1, 4, GROUP>(a, pl, t, lds, f0, f1);
     } else {
@@ -845,7 +898,7 @@ static hipError_t launch_dma_variant(const TiledArgs& a, int groups, int nload, 
     configured_lds = a.ring_bytes;
   }
   hipLaunchKernelGGL((remap_tiled_dma_kernel<VARIANT, KS>), dim3(a.total_tiles, groups, 1), dim3(256 + 64 * nload),
-                     (size_t)a.ring_bytes, stream, a);
+                     (size_t)a.ring_bytes + ((VARIANT & 16) ? 64 : 0), stream, a);
   return hipGetLastError();
 }
 
@@ -898,6 +951,7 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
   if (a.ks == 1) return launch_dma_variant<1, 1>(a, groups, nload, stream);
   if (a.ks == 2) return launch_dma_variant<1, 2>(a, groups, nload, stream);
   if (a.ks == 8) return launch_dma_variant<1, 8>(a, groups, nload, stream);
+  if ((a.variant & 16) && nload == 1) return launch_dma_variant<17, 4>(a, groups, nload, stream);
   switch (a.variant & 3) {
     case 0: return launch_dma_variant<0, 4>(a, groups, nload, stream);
     case 1: return launch_dma_variant<1, 4>(a, groups, nload, stream);

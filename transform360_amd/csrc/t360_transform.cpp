@@ -193,7 +193,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
   }
   if (getenv("T360_NO_DMA")) use_dma_ = false;
-  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 15;
+  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 31;
   if (const char* e = getenv("T360_LOADERS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) loader_waves_ = v;
