@@ -631,6 +631,12 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_self_kernel(TiledArgs a
 template <int VARIANT, int KS>
 __global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_dma_kernel(TiledArgs a) {
   constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
+  // VARIANT bit 5: the instrumented build (T360_DEBUG / T360_TRACE).  In the production build the
+  // switches are compile-time zero, so none of their branches is left in the frame loops.
+  if (!(VARIANT & 32)) {
+    a.debug = 0;
+    a.trace = nullptr;
+  }
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
   int b = xcd_contiguous(blockIdx.x, a.total_tiles);
   // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
@@ -948,15 +954,20 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
       hipLaunchKernelGGL(remap_tiled_cubic_persist_kernel<0>, dim3(grid), dim3(256 + 64 * nload), (size_t)a.ring_bytes, stream, p);
     return hipGetLastError();
   }
-  if (a.ks == 1) return launch_dma_variant<1, 1>(a, groups, nload, stream);
-  if (a.ks == 2) return launch_dma_variant<1, 2>(a, groups, nload, stream);
-  if (a.ks == 8) return launch_dma_variant<1, 8>(a, groups, nload, stream);
+  const bool instrumented = a.debug != 0 || a.trace != nullptr;
+  if (a.ks == 1) return instrumented ? launch_dma_variant<33, 1>(a, groups, nload, stream) : launch_dma_variant<1, 1>(a, groups, nload, stream);
+  if (a.ks == 2) return instrumented ? launch_dma_variant<33, 2>(a, groups, nload, stream) : launch_dma_variant<1, 2>(a, groups, nload, stream);
+  if (a.ks == 8) return instrumented ? launch_dma_variant<33, 8>(a, groups, nload, stream) : launch_dma_variant<1, 8>(a, groups, nload, stream);
   if ((a.variant & 16) && nload == 1) return launch_dma_variant<17, 4>(a, groups, nload, stream);
-  switch (a.variant & 3) {
+  switch ((a.variant & 3) | (instrumented ? 32 : 0)) {
     case 0: return launch_dma_variant<0, 4>(a, groups, nload, stream);
     case 1: return launch_dma_variant<1, 4>(a, groups, nload, stream);
     case 2: return launch_dma_variant<2, 4>(a, groups, nload, stream);
-    default: return launch_dma_variant<3, 4>(a, groups, nload, stream);
+    case 3: return launch_dma_variant<3, 4>(a, groups, nload, stream);
+    case 32: return launch_dma_variant<32, 4>(a, groups, nload, stream);
+    case 34: return launch_dma_variant<34, 4>(a, groups, nload, stream);
+    case 35: return launch_dma_variant<35, 4>(a, groups, nload, stream);
+    default: return launch_dma_variant<33, 4>(a, groups, nload, stream);
   }
 }
 
