@@ -447,10 +447,13 @@ __device__ __forceinline__ void loader_wave(const TiledArgs& a, const TiledPlane
   if (which == 0 && !(a.debug & (32 | 16))) trace_mark(a, 6);
 }
 
-template <int NPX, int KS, int GROUP, bool FLAGS = false>
+// CPR > 0: the tile's LDS row pitch (16 * CPR bytes) is a compile-time constant, so the four stencil
+// rows of a pixel are immediate offsets of ONE address (12 v_add fewer per 4 pixels); 0 = run time.
+template <int NPX, int KS, int GROUP, bool FLAGS = false, int CPR = 0>
 __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
                                                const uint8_t* __restrict__ lds, int f0, int f1) {
-  const RingGeom g = ring_geom(t, a.ring_bytes);
+  RingGeom g = ring_geom(t, a.ring_bytes);
+  if (CPR > 0) g.pitch = CPR * kStageChunk;
   PixelSetup<NPX, KS> px;
   load_pixels<NPX, KS>(pl, a.wpack, t, g.pitch, px, a.debug);
   if (a.trace && !(a.debug & 16)) {
@@ -674,9 +677,24 @@ __global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_dma_ke
     loader_wave<FLAGS>(a, pl, t, (uint32_t)(uintptr_t)lds, f0, f1, wave - kLoaderWave, (int)(blockDim.x >> 6) - kLoaderWave,
                        ring_ctrl(lds, a.ring_bytes));
   } else if (KS == 8 || t.kind == kTileStaged16) {
-    consumer_waves<1, KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1);  // Lanczos4 is planned as 16x16 tiles only (32 weight VGPRs per pixel)
+    // Lanczos4 is planned as 16x16 tiles only (32 weight VGPRs per pixel)
+    if (KS == 4 && !FLAGS && t.cpr == 4)
+      consumer_waves<1, KS, GROUP, FLAGS, (KS == 4 ? 4 : 0)>(a, pl, t, lds, f0, f1);
+    else
+      consumer_waves<1, KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1);
   } else {
-    consumer_waves<(KS == 8 ? 1 : 4), KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1);  // 32x32 tiles and 128x8 strips
+    // 32x32 tiles and 128x8 strips; the common pitches of the bicubic workloads are specialised
+    constexpr int N4 = KS == 8 ? 1 : 4;
+    constexpr bool SPEC = KS == 4 && !FLAGS;
+    switch (SPEC ? (int)t.cpr : 0) {
+      case 4: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 4 : 0>(a, pl, t, lds, f0, f1); break;
+      case 5: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 5 : 0>(a, pl, t, lds, f0, f1); break;
+      case 6: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 6 : 0>(a, pl, t, lds, f0, f1); break;
+      case 10: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 10 : 0>(a, pl, t, lds, f0, f1); break;
+      case 11: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 11 : 0>(a, pl, t, lds, f0, f1); break;
+      case 12: consumer_waves<N4, KS, GROUP, FLAGS, SPEC ? 12 : 0>(a, pl, t, lds, f0, f1); break;
+      default: consumer_waves<N4, KS, GROUP, FLAGS>(a, pl, t, lds, f0, f1); break;
+    }
   }
 }
 
