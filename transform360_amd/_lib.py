@@ -10,7 +10,8 @@ import subprocess
 from .abi import FrameTransformContext
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libTransform360.so")
+# T360_LIB: A/B runs of two builds inside one gpurun call (tools/); never set in production
+LIB_PATH = os.environ.get("T360_LIB") or os.path.join(_PKG, "lib", "libTransform360.so")
 CSRC_DIR = os.path.join(_PKG, "csrc")
 
 # every symbol include/Transform360/VideoFrameTransformHandler.h and t360_device.h declare

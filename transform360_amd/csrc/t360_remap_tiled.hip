@@ -198,9 +198,13 @@ __device__ __forceinline__ void gather_store(const PixelSetup<NPX, KS>& s, const
       const uint32_t w = __builtin_amdgcn_perm(b1, b0, sel_lo) | __builtin_amdgcn_perm(b3, b2, sel_hi);
       *reinterpret_cast<uint32_t*>(d) = w;
     } else {
+      // partial tiles only: keep the row stride opaque here, or hipcc turns d + p*dstride into three
+      // more 64-bit induction variables that the (hot) dword path then updates every frame
+      int rs = dstride;
+      asm volatile("" : "+s"(rs));
 #pragma unroll
       for (int p = 0; p < NPX; p++)
-        if (s.live[p]) d[(size_t)p * dstride] = (uint8_t)v[p];
+        if (s.live[p]) d[(size_t)p * rs] = (uint8_t)v[p];
     }
   } else {
     if (s.live[0]) d[0] = (uint8_t)v[0];
