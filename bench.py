@@ -145,12 +145,21 @@ def main():
                              % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the remap path)"
-    torch.cuda.set_device(local_rank)
+    # T360_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then
+    # share devices and the few collectives around the path run on CPU tensors); the driver's runs use
+    # nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("T360_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = workload(args.config)
     in_w, in_h = wl["in_w"], wl["in_h"]
@@ -159,7 +168,7 @@ def main():
                                  ctx.output_stereo_format)
     if dist is not None:
         # init state: rank 0's 112-byte context is broadcast over RCCL; every rank rebuilds maps from it
-        buf = torch.frombuffer(bytearray(bytes(ctx)), dtype=torch.uint8).cuda()
+        buf = torch.frombuffer(bytearray(bytes(ctx)), dtype=torch.uint8).to(coll_dev)
         dist.broadcast(buf, src=0)
         ctx = FrameTransformContext.from_buffer_copy(bytes(buf.cpu().numpy()))
 
@@ -209,13 +218,13 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     luma_ms = [a.elapsed_time(b) for a, b in events]
 
     # verification outside the timed region: per-rank checksum of the outputs, gathered on rank 0
-    csum = torch.sum(d_out.view(-1).to(torch.int64)).reshape(1)
+    csum = torch.sum(d_out.view(-1).to(torch.int64)).reshape(1).to(coll_dev)
     if dist is not None:
         allc = [torch.zeros_like(csum) for _ in range(world)]
         dist.all_gather(allc, csum)
