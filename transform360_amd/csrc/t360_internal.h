@@ -84,6 +84,9 @@ enum : int {
   kTileStrip128 = 3,  // 128x8 output px, 4 px per lane: ~330-byte source row fragments, which the
                       // memory system streams at ~6 TB/s where 96-byte fragments reach ~3 TB/s
                       // (tools/ubench/fragment_bw.hip)
+  kTileWide64 = 4,    // 64x16 output px, 4 px per lane (lane = column, 4 bands of 4 rows): same pixels per
+                      // workgroup as a 32x32 tile with half the horizontal box borders (halo + 16-byte alignment
+                      // cost ~29 bytes per ~60-byte row of a 32x32 tile, the 3 halo rows only ~10 % of its height)
   kTileStaged16 = 1,  // 16x16 output px, 1 px per lane, source box staged through LDS
   kTileDirect16 = 2,  // 16x16 output px, gathers straight from global memory (box too large)
 };

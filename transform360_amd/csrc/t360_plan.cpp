@@ -72,9 +72,15 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
   std::vector<TileDesc> tiles, direct;
   tiles.reserve(nregions * 4);
   int64_t tlut_words = 0, staged_bytes = 0;
-  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0;
+  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0, nwide = 0;
   // 128x8 strips give ~330-byte row fragments (better for HBM) but measured ~4 % slower end to end
   // while the kernel is VALU-issue-bound; opt-in until that changes (DESIGN.md, round-1 notes)
+  // 64x16 tiles replace pairs of 32x32 tiles unless they would stage more than wide_pct % of the pair's
+  // bytes (T360_WIDE64=0 turns them off).  Measured on config 2: 6-7 % faster end to end at 150-1000 %
+  // although more bytes go through LDS -- the ~160-byte row fragments and the halved number of
+  // horizontal box borders are what the fabric and HBM see.
+  const int wide_pct = getenv("T360_WIDE64") ? atoi(getenv("T360_WIDE64")) : 200;
+  const bool wide64 = wide_pct > 0 && (ksize == 2 || ksize == 4);  // nearest has no halo to save, Lanczos4 is 16x16 only
   const int strips_mode = getenv("T360_STRIPS") ? atoi(getenv("T360_STRIPS")) : 0;  // 2: wherever a strip fits (experiment)
   const bool allow_strips = strips_mode > 0;
   const int pad_mode = getenv("T360_PAD") ? atoi(getenv("T360_PAD")) : 1;
@@ -114,7 +120,7 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
     }
     tlut_words += kind == kTileStaged16 ? 256 : 1024;
     staged_bytes += (int64_t)cpr * kStageChunk * bx.rows;
-    (kind == kTileStaged16 ? n16 : kind == kTileStaged32 ? n32 : nstrip)++;
+    (kind == kTileStaged16 ? n16 : kind == kTileStaged32 ? n32 : kind == kTileWide64 ? nwide : nstrip)++;
     tiles.push_back(t);
   };
   // Emission order = execution order (each XCD gets a contiguous range).  Region rows are walked in
@@ -157,8 +163,41 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
           if (!strip[k].empty) emit(strip[k], kTileStrip128, ox, oy + 8 * k, 128, 8);
         continue;
       }
+      // option C: per half region (64x32 output px) two 64x16 tiles instead of two 32x32 tiles when they
+      // stage fewer bytes; their boxes are the unions of the scanned 16x16 quadrant boxes
+      bool half_done[2] = {false, false};
+      if (wide64) {
+        for (int h = 0; h < 2; h++) {
+          const Box& ta = tile[2 * h];
+          const Box& tb = tile[2 * h + 1];
+          if (ta.empty || tb.empty || !ta.fits || !tb.fits) continue;
+          Box w[2];
+          bool ok = true;
+          int64_t wide_bytes = 0;
+          for (int v = 0; v < 2 && ok; v++) {
+            int u[6] = {1 << 30, -(1 << 30), 1 << 30, -(1 << 30), 1 << 30, -(1 << 30)};
+            for (int t2 = 0; t2 < 2; t2++)
+              for (int qx = 0; qx < 2; qx++) {
+                const int* q = b + 6 * (8 + 4 * (2 * h + t2) + 2 * v + qx);
+                if (q[0] > q[1]) continue;  // empty quadrant (plane edge)
+                u[0] = std::min(u[0], q[0]); u[1] = std::max(u[1], q[1]);
+                u[2] = std::min(u[2], q[2]); u[3] = std::max(u[3], q[3]);
+                u[4] = std::min(u[4], q[4]); u[5] = std::max(u[5], q[5]);
+              }
+            w[v] = make_box(u, halo_lo, halo_hi, max_chunks);
+            ok = !w[v].empty && w[v].fits;
+            if (ok) wide_bytes += (int64_t)w[v].cpr * kStageChunk * w[v].rows;
+          }
+          const int64_t sq_bytes = (int64_t)ta.cpr * kStageChunk * ta.rows + (int64_t)tb.cpr * kStageChunk * tb.rows;
+          if (ok && wide_bytes * 100 <= sq_bytes * wide_pct) {
+            emit(w[0], kTileWide64, ox + 64 * h, oy, 64, 16);
+            emit(w[1], kTileWide64, ox + 64 * h, oy + 16, 64, 16);
+            half_done[h] = true;
+          }
+        }
+      }
       for (int k = 0; k < 4; k++) {
-        if (tile[k].empty) continue;
+        if (tile[k].empty || half_done[k >> 1]) continue;
         if (tile[k].fits) {
           emit(tile[k], kTileStaged32, ox + 32 * k, oy, 32, 32);
           continue;
@@ -197,6 +236,7 @@ bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, in
            "%d direct, %.2f MB staged per plane (%.2fx the source plane)\n",
            dw, dh, sw, sh, plan->ntiles, nstrip, n32, n16, ndirect, staged_bytes / 1e6,
            (double)staged_bytes / ((double)sw * sh));
+  if (getenv("T360_VERBOSE") && nwide) printf("transform360:   %d tiles 64x16\n", nwide);
   if (getenv("T360_VERBOSE")) {
     printf("transform360:   chunks per row (16 B each): ");
     for (int c = 0; c < 64; c++)

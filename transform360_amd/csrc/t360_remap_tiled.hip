@@ -219,8 +219,8 @@ __device__ __forceinline__ size_t out_pos(const TiledPlane& pl, const TileDesc& 
   const int tid = threadIdx.x;
   int ox, oy;
   if (NPX == 4) {
-    // 32x32 tile: 32 columns x 8 bands of 4 rows; 128x8 strip: 128 columns x 2 bands of 4 rows
-    const int logw = t.kind == kTileStrip128 ? 7 : 5;
+    // 32x32 tile: 32 columns x 8 bands of 4 rows; 64x16: 64 columns x 4 bands; 128x8 strip: 128 columns x 2 bands
+    const int logw = t.kind == kTileStrip128 ? 7 : (t.kind == kTileWide64 ? 6 : 5);
     const int x = tid & ((1 << logw) - 1), band = tid >> logw;
     if (dword_store) {
       ox = t.ox + (x & ~3);

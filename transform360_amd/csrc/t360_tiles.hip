@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void tile_lut_kernel(const LutEntry* __restric
     } else if (t.kind == kTileStrip128) {
       ox = t.ox + (tid & 127);
       oy = t.oy + (tid >> 7) * 4 + p;
+    } else if (t.kind == kTileWide64) {
+      ox = t.ox + (tid & 63);
+      oy = t.oy + (tid >> 6) * 4 + p;
     } else {
       ox = t.ox + (tid & 15);
       oy = t.oy + (tid >> 4);
