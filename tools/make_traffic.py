@@ -24,7 +24,7 @@ for path in glob.glob(os.path.join(pmc, "*", "*counter_collection.csv")):
     with open(path) as f:
         for row in csv.DictReader(f):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-name = max((k for k in acc if "remap_tiled_cubic_dma_kernel" in k or "remap_gather_kernel" in k),
+name = max((k for k in acc if "remap_tiled" in k or "remap_gather_kernel" in k),
            key=lambda k: sum(acc[k].get("TCC_EA0_RDREQ_sum", [0])), default=None)
 if name is None:
     sys.exit("no gather kernel found in %s" % pmc)
