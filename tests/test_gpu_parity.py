@@ -239,7 +239,7 @@ def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
     {"T360_VARIANT": "0"}, {"T360_VARIANT": "4"}, {"T360_VARIANT": "5"}, {"T360_VARIANT": "9"}, {"T360_VARIANT": "17"},
     {"T360_STRIPS": "1"}, {"T360_PAD": "0"}, {"T360_PAD": "2"}, {"T360_PAD": "3"}, {"T360_NO_DMA": "1"},
     {"T360_LOADERS": "2"}, {"T360_FRAMES_PER_BLOCK": "2"}, {"T360_RING_KB": "24"}, {"T360_RING_KB": "80"},
-    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"}, {"T360_WIDE64": "0"}, {"T360_WIDE64": "1000"}, {"T360_BAND": "1"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_kernel_variants_are_bit_identical(env, T, oracle_mod, monkeypatch):
     for k, v in env.items():
