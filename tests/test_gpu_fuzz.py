@@ -1,0 +1,111 @@
+"""Randomised differential test: the HIP path against the oracle over the whole configuration surface.
+
+Every case draws a context (layouts, stereo packings, interpolation, rotation, off-centre cube,
+low-pass segmentation, supersample factors), plane sizes and strides from a seeded generator and
+compares ONE plane through the reference ABI bit for bit.  Sizes are small enough for the oracle to
+finish in milliseconds; the seeds are fixed, so a failure names a reproducible case.
+"""
+import numpy as np
+import pytest
+
+from transform360_amd.abi import (CUBIC, LANCZOS4, LAYOUT_BARREL, LAYOUT_BARREL_SPLIT, LAYOUT_CUBEMAP_23_OFFCENTER,
+                                  LAYOUT_CUBEMAP_32, LAYOUT_EAC_32, LAYOUT_EQUIRECT, LAYOUT_FLAT_FIXED, LINEAR, NEAREST,
+                                  STEREO_FORMAT_LR, STEREO_FORMAT_MONO, STEREO_FORMAT_TB, filter_defaults)
+
+pytestmark = pytest.mark.gpu
+
+OUT_LAYOUTS = [LAYOUT_CUBEMAP_32, LAYOUT_CUBEMAP_32, LAYOUT_CUBEMAP_23_OFFCENTER, LAYOUT_FLAT_FIXED, LAYOUT_EQUIRECT,
+               LAYOUT_BARREL, LAYOUT_BARREL_SPLIT, LAYOUT_EAC_32]
+
+
+def draw(seed):
+    r = np.random.default_rng(seed)
+    ov = {}
+    ov["output_layout"] = int(r.choice(OUT_LAYOUTS))
+    ov["input_layout"] = LAYOUT_CUBEMAP_32 if r.random() < 0.15 else LAYOUT_EQUIRECT
+    stereo = int(r.choice([STEREO_FORMAT_MONO, STEREO_FORMAT_MONO, STEREO_FORMAT_TB, STEREO_FORMAT_LR]))
+    ov["input_stereo_format"] = stereo
+    ov["output_stereo_format"] = stereo if r.random() < 0.7 else int(r.choice([STEREO_FORMAT_TB, STEREO_FORMAT_LR, STEREO_FORMAT_MONO]))
+    ov["vflip"] = int(r.random() < 0.2)
+    ov["interpolation_alg"] = int(r.choice([NEAREST, LINEAR, CUBIC, CUBIC, LANCZOS4]))
+    ov["expand_coef"] = float(np.float32(r.choice([1.0, 1.01, 1.05])))
+    ov["input_expand_coef"] = float(np.float32(r.choice([1.0, 1.01])))
+    if r.random() < 0.5:
+        ov["fixed_yaw"] = float(np.float32(r.uniform(-180, 180)))
+        ov["fixed_pitch"] = float(np.float32(r.uniform(-90, 90)))
+        ov["fixed_roll"] = float(np.float32(r.uniform(-45, 45)))
+    if r.random() < 0.3:
+        ov["fixed_cube_offcenter_z"] = float(np.float32(r.uniform(-0.5, 0.5)))
+        ov["fixed_cube_offcenter_y"] = float(np.float32(r.uniform(-0.3, 0.3)))
+        ov["is_horizontal_offset"] = int(r.random() < 0.3)
+    lpf = r.random() < 0.45
+    ov["enable_low_pass_filter"] = int(lpf)
+    if lpf:
+        ov["num_vertical_segments"] = int(r.integers(1, 9))
+        ov["num_horizontal_segments"] = int(r.integers(1, 6))
+        ov["adjust_kernel"] = int(r.random() < 0.7)
+        ov["kernel_height_scale_factor"] = float(np.float32(r.choice([0.5, 1.0, 2.0, 4.0])))
+    if r.random() < 0.25:
+        ov["width_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 3.0, 1.5, 1.25])))
+        ov["height_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 1.5, 2.5])))
+    # plane sizes: mostly 16-byte friendly (tiled DMA path), sometimes odd (general gather)
+    if r.random() < 0.75:
+        in_w, in_h = int(r.integers(8, 40)) * 16, int(r.integers(6, 30)) * 8
+        pin = int(r.choice([0, 16, 64]))
+    else:
+        in_w, in_h = int(r.integers(100, 600)), int(r.integers(60, 300))
+        pin = int(r.integers(0, 9))
+    out_w, out_h = int(r.integers(4, 28)) * 12, int(r.integers(4, 24)) * 8
+    pout = int(r.choice([0, 0, 4, 13]))
+    return ov, (in_w, in_h, out_w, out_h), pin, pout
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_configuration_matches_oracle(seed, oracle_mod):
+    import torch
+
+    from transform360_amd import handler as T
+    O = oracle_mod
+    ov, dims, pin, pout = draw(1000 + seed)
+    in_w, in_h, out_w, out_h = dims
+    ctx = filter_defaults(**ov)
+    rng = np.random.default_rng(seed)
+    src_full = rng.integers(0, 256, (in_h, in_w + pin), dtype=np.uint8)
+    src = src_full[:, :in_w]
+    o = O.Oracle(ctx, threads=2)
+    ok_o = o.generateMapForPlane(*dims, 0)
+    want = np.full((out_h, out_w), 0xA5, np.uint8)
+    ok_o = ok_o and o.transformFramePlane(src, want, 0)
+    dsrc = torch.from_numpy(src_full).cuda()[:, :in_w]
+    dfull = torch.full((out_h, out_w + pout), 0xA5, dtype=torch.uint8, device="cuda")
+    ddst = dfull[:, :out_w]
+    torch.cuda.synchronize()
+    with T.VideoFrameTransform(ctx) as t:
+        ok_g = t.generateMapForPlane(*dims, 0) and t.transformFramePlane(dsrc, ddst, 0, 0)
+    if not ok_o:
+        # the oracle refuses what it does not restate (INTER_AREA enlargement cannot occur here);
+        # then the HIP path must refuse too rather than invent an answer
+        assert not ok_g, "oracle refused %r but the HIP path produced output" % (ov,)
+        return
+    assert ok_g, "HIP path refused %r %r" % (ov, dims)
+    got = ddst.cpu().numpy()
+    diff = got.astype(int) - want.astype(int)
+    assert not diff.any(), "seed %d %r dims %r: %d px differ, max |d| %d" % (
+        seed, ov, dims, np.count_nonzero(diff), np.abs(diff).max())
+    assert (dfull[:, out_w:] == 0xA5).all().item()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_batches_match_oracle(seed, oracle_mod):
+    """yuv420p batches through T360_transformFrames: frame counts around the frames-per-workgroup
+    boundary, all three planes fused, against per-plane oracle calls."""
+    from tests.test_gpu_parity import _batch_case
+    from transform360_amd import handler as T
+    ov, _, _, _ = draw(5000 + seed)
+    for k in ("width_scale_factor", "height_scale_factor"):   # covered per plane above; keep batches quick
+        ov.pop(k, None)
+    r = np.random.default_rng(seed)
+    in_w, in_h = int(r.integers(6, 24)) * 32, int(r.integers(6, 20)) * 16
+    out_w, out_h = int(r.integers(3, 16)) * 24, int(r.integers(3, 12)) * 16
+    n = int(r.choice([1, 2, 3, 15, 16, 17, 20]))
+    _batch_case(T, oracle_mod, ov, n=n, dims=(in_w, in_h, out_w, out_h), extra_pad=int(r.choice([0, 0, 64, 40])))

@@ -216,7 +216,8 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64):
             assert np.array_equal(fin, T.noise_bytes(lin.frame_bytes, T.frame_seed(k)))
             fout = h_out[k * lout.frame_bytes:(k + 1) * lout.frame_bytes]
             for p in range(3):
-                want = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
+                # same initial content as d_out: BARREL outputs (BORDER_TRANSPARENT) leave unmapped pixels alone
+                want = np.full((lout.dims[p][1], lout.dims[p][0]), 0x5A, np.uint8)
                 assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
                 assert np.array_equal(lout.plane_view(fout, p), want), (k, p)
 
