@@ -64,8 +64,8 @@ struct TiledArgs {
   int ring_bytes;           // LDS ring of the DMA-staged kernel
   int loader_waves;         // DMA loader waves per workgroup (1..4) next to the 4 consumer waves
   int debug;                // experiments (T360_DEBUG): bit2 no steady-state DMA, bit3 no gather
-  int variant;              // DMA kernel build: bit0 LDS reads in groups of 2 px, bit1 register cap for 6 waves/SIMD,
-                            // bit2 no loader wave, bit3 persistent workgroups
+  int variant;              // DMA kernel build: bit0 LDS reads in groups of 2 px, bit2 no loader wave,
+                            // bit3 persistent workgroups, bit4 LDS flags instead of the frame barrier
   unsigned long long* trace;  // optional: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   int* work_counters;       // persistent variant (bit3): 8 zeroed ints, one item queue per XCD
   int persist_slots;        // persistent variant: workgroups to launch (resident slots of the device)

@@ -632,11 +632,11 @@ __global__ __launch_bounds__(256) void remap_tiled_cubic_self_kernel(TiledArgs a
     self_loading_waves<4, GROUP>(a, pl, t, lds, f0, f1);
 }
 
-// VARIANT bit 0: LDS reads in groups of 2 pixels instead of 4 (fewer registers);
-//         bit 1: cap registers for 6 waves per SIMD (4 workgroups of 5 waves per CU)
+// VARIANT bit 0: LDS reads in groups of 2 pixels instead of 4 (78 instead of 92 VGPRs: 4 workgroups per CU);
+//         bit 4: LDS flags instead of the per-frame barrier; bit 5: instrumented (debug / trace) build
 //         KS: taps per axis of the interpolation (1, 2, 4, 8)
 template <int VARIANT, int KS>
-__global__ __launch_bounds__(512, (VARIANT & 2) ? 6 : 1) void remap_tiled_dma_kernel(TiledArgs a) {
+__global__ __launch_bounds__(512, 1) void remap_tiled_dma_kernel(TiledArgs a) {
   constexpr int GROUP = (VARIANT & 1) ? 2 : 4;
   // VARIANT bit 5: the instrumented build (T360_DEBUG / T360_TRACE).  In the production build the
   // switches are compile-time zero, so none of their branches is left in the frame loops.
@@ -981,14 +981,10 @@ hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream) 
   if (a.ks == 2) return instrumented ? launch_dma_variant<33, 2>(a, groups, nload, stream) : launch_dma_variant<1, 2>(a, groups, nload, stream);
   if (a.ks == 8) return instrumented ? launch_dma_variant<33, 8>(a, groups, nload, stream) : launch_dma_variant<1, 8>(a, groups, nload, stream);
   if ((a.variant & 16) && nload == 1) return launch_dma_variant<17, 4>(a, groups, nload, stream);
-  switch ((a.variant & 3) | (instrumented ? 32 : 0)) {
+  switch ((a.variant & 1) | (instrumented ? 32 : 0)) {
     case 0: return launch_dma_variant<0, 4>(a, groups, nload, stream);
     case 1: return launch_dma_variant<1, 4>(a, groups, nload, stream);
-    case 2: return launch_dma_variant<2, 4>(a, groups, nload, stream);
-    case 3: return launch_dma_variant<3, 4>(a, groups, nload, stream);
     case 32: return launch_dma_variant<32, 4>(a, groups, nload, stream);
-    case 34: return launch_dma_variant<34, 4>(a, groups, nload, stream);
-    case 35: return launch_dma_variant<35, 4>(a, groups, nload, stream);
     default: return launch_dma_variant<33, 4>(a, groups, nload, stream);
   }
 }

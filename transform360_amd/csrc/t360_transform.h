@@ -128,7 +128,7 @@ class VideoFrameTransform {
                                 // (VGPR-limited, measured), 3 x 48 KiB fits the 160 KiB LDS
   bool use_dma_ = true;
   int loader_waves_ = 1;
-  int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit1 register cap, bit2 no loader wave
+  int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit2 no loader wave, bit3 persistent, bit4 flags
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer work_counters_;  // item queues of the persistent gather kernel (8 ints)
