@@ -1,0 +1,47 @@
+"""Randomised pinning of the oracle against the reference's own code (oracle/_ref).
+
+oracle/_ref is the reference's VideoFrameTransform.cpp compiled unmodified (projection, low-pass
+configuration, frame orchestration); its cv:: calls run the oracle's restatement of OpenCV.  For
+contexts drawn from the whole configuration space the oracle must reproduce: the warp map bit for
+bit, the low-pass segments and kernels, and the output plane.  (Runs wherever the prebuilt
+oracle/_ref/libt360ref.so is present; it never reads /root/reference.)
+"""
+import numpy as np
+import pytest
+
+from tests.test_gpu_fuzz import draw
+from transform360_amd.abi import filter_defaults
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_oracle_equals_reference_build(seed, oracle_mod):
+    O = oracle_mod
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    ov, dims, pin, pout = draw(9000 + seed)
+    in_w, in_h, out_w, out_h = dims
+    ctx = filter_defaults(**ov)
+    r, o = O.Ref(ctx), O.Oracle(ctx, threads=2)
+    ok_r, ok_o = r.generateMapForPlane(*dims, 0), o.generateMapForPlane(*dims, 0)
+    assert ok_r == ok_o
+    if not ok_r:
+        return
+    mr, mo = r.map(0), o.map(0)
+    assert mr.shape == mo.shape
+    assert np.array_equal(mr.view(np.uint32), mo.view(np.uint32)), "warp map bits differ for %r %r" % (ov, dims)
+    if ctx.enable_low_pass_filter:
+        sr, so = r.segments(0), o.segments(0)
+        assert len(sr) == len(so)
+        for a, b in zip(sr, so):   # (left, top, width, height, kx, ky)
+            assert tuple(a[:4]) == tuple(b[:4])
+            for ka, kb in ((a[4], b[4]), (a[5], b[5])):
+                assert np.array_equal(np.asarray(ka, np.float32).view(np.uint32), np.asarray(kb, np.float32).view(np.uint32))
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, 256, (in_h, in_w + pin), dtype=np.uint8)[:, :in_w]
+    dr = np.full((out_h, out_w + pout), 0xA5, np.uint8)[:, :out_w]
+    do = np.full((out_h, out_w + pout), 0xA5, np.uint8)[:, :out_w]
+    ok_r, ok_o = r.transformFramePlane(src, dr, 0), o.transformFramePlane(src, do, 0)
+    assert ok_r == ok_o, "reference build %s, oracle %s for %r" % (ok_r, ok_o, ov)
+    if ok_r:
+        assert np.array_equal(dr, do), "%d px differ for %r %r" % (np.count_nonzero(dr != do), ov, dims)
+    r.close()
