@@ -249,7 +249,7 @@ def main():
             except (OSError, ValueError):
                 traffic = None
         res = {
-            "metric": "Mpix/s remapped (4K equirect->512-edge cubemap, bicubic)" if args.config == 2
+            "metric": "Mpix/s remapped (4K equirect\u2192512-edge cubemap, bicubic)" if args.config == 2
                       else "Mpix/s remapped (%s)" % wl["name"],
             "value": round(fps * out_mpix, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
