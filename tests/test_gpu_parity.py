@@ -385,3 +385,63 @@ def test_c_harness_replays_filter_sequence(T, oracle_mod, tmp_path):
             assert l[4] == "%dx%d" % (ow, oh)
             assert l[6] == hx(O.fnv1a64(want)), "frame %d plane %d differs from the oracle" % (f, plane)
             assert l[8] == "intact"
+
+
+# ---------------------------------------------------------------- handle lifecycle / independence
+def test_handles_are_independent_across_host_threads(T, oracle_mod):
+    """one handle is used from one thread, DISTINCT handles must be independent.  Two host
+    threads run their own handle (different interpolation, own stream) at the same time."""
+    import threading
+
+    import torch
+    O = oracle_mod
+    dims = (960, 480, 384, 256)
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (dims[1], dims[0]), dtype=np.uint8)
+    dsrc = dev(src)
+    results, errors = {}, []
+
+    def work(interp):
+        try:
+            ctx = filter_defaults(interpolation_alg=interp, enable_low_pass_filter=int(interp == CUBIC))
+            with T.VideoFrameTransform(ctx) as t:
+                assert t.generateMapForPlane(*dims, 0)
+                outs = []
+                for _ in range(20):
+                    dst = torch.zeros((dims[3], dims[2]), dtype=torch.uint8, device="cuda")
+                    torch.cuda.synchronize()
+                    assert t.transformFramePlane(dsrc, dst, 0)
+                    outs.append(dst.cpu().numpy())
+                results[interp] = outs
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((interp, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in (CUBIC, LANCZOS4, NEAREST)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for interp, outs in results.items():
+        o = O.Oracle(filter_defaults(interpolation_alg=interp, enable_low_pass_filter=int(interp == CUBIC)), threads=2)
+        assert o.generateMapForPlane(*dims, 0)
+        want = np.zeros((dims[3], dims[2]), np.uint8)
+        assert o.transformFramePlane(src, want, 0)
+        for got in outs:
+            assert np.array_equal(got, want), interp
+
+
+def test_handle_churn_does_not_leak_device_memory(T):
+    import torch
+    torch.cuda.synchronize()
+
+    def cycle(n):
+        for _ in range(n):
+            with T.VideoFrameTransform(filter_defaults()) as t:
+                assert t.generateMapForPlane(960, 480, 384, 256, 0)
+                assert t.generateMapForPlane(480, 240, 192, 128, 1)
+    cycle(3)
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(25)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 25 handle lifetimes" % ((free0 - free1) >> 20)
