@@ -1,10 +1,12 @@
-// t360_remap_tiled.hip -- LDS-tiled bicubic gather over a batch of frames (the hot kernels).
+// t360_remap_tiled.hip -- LDS-tiled gather over a batch of frames (the hot kernels).
 //
-// Same arithmetic as t360_remap.hip (cv::remap INTER_CUBIC, BORDER_WRAP, Q15 weights,
-// (sum + 16384) >> 15), organised for MI355X:
+// Same arithmetic as t360_remap.hip (cv::remap, BORDER_WRAP, Q15 weights, (sum + 16384) >> 15,
+// SURVEY.md Appendix A.3/A.4); written around the bicubic 4x4 stencil and instantiated for nearest,
+// bilinear and Lanczos4 as well.  Organised for MI355X:
 //
-//   * one 256-lane workgroup owns one OUTPUT tile (32x32 px, 4 px per lane; 16x16 px, 1 px per
-//     lane near the poles) and walks `frames_per_block` frames of the batch with it.  Everything
+//   * one workgroup (4 consumer waves + 1 loader wave) owns one OUTPUT tile (64x16 or 32x32 px,
+//     4 px per lane, lane = column; 16x16 px, 1 px per lane near the poles; the tile shape is the
+//     plan's choice, t360_plan.cpp) and walks `frames_per_block` frames of the batch with it.  Everything
 //     that depends only on geometry -- the lane's LDS read addresses, its 16 Q15 weights per
 //     pixel, the addresses of the source chunks it stages -- is computed ONCE per tile and kept
 //     in registers for all frames: per frame a lane only moves bytes and issues dot products.
