@@ -80,6 +80,20 @@ int T360_getSegment(VideoFrameTransform* transform, int map_index, int i, int* r
                     int* fixed_point);
 int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i, float* kx, float* ky);
 
+/* ---- what ran (benchmark reporting) ---- */
+
+/* Name of the gather kernel the most recent transform call of this handle launched, e.g.
+ * "remap_tiled_kernel<4, 8, 2>" (taps per axis, staging budget in KiB per tile and copy, ring slots) or
+ * "remap_gather_kernel"; "" before the first call.  The string lives as long as the handle. */
+const char* T360_lastKernel(VideoFrameTransform* transform);
+/* Gather plan of `map_index`: stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
+ * by the staged tiles, bytes of LDS filled per frame (one copy), pixels in direct tiles, bytes of the tile
+ * tables on the device, 0, 0.  Returns 0 when the plane has no tile plan (it then uses the general gather). */
+int T360_getPlanStats(VideoFrameTransform* transform, int map_index, int64_t* stats8);
+/* 0 for the shipped library.  Non-zero for a library compiled with -DT360_INSTRUMENT, which reads tuning
+ * switches from the environment (development only; bench.py refuses to report numbers from it). */
+int T360_buildFlags(void);
+
 /* ---- synthetic stream generator (benchmark / tests) ---- */
 
 /* Fill device memory with counter-based noise: byte i = top 8 bits of

@@ -7,6 +7,8 @@ use the oracle's integer formulation, so the tests below demand BIT-EXACT equali
 oracle everywhere; the +-1 LSB is left to the oracle-vs-real-OpenCV uncertainty
 (oracle/t360_oracle_cv.c header).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -188,7 +190,7 @@ def test_filter_call_sequence_yuv420p(T, oracle_mod):
 
 
 # ---------------------------------------------------------------- batch entry point
-def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64):
+def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=4):
     """n frames x 3 planes through T360_transformFrames == per-plane oracle calls."""
     import torch
     in_w, in_h, out_w, out_h = dims
@@ -200,7 +202,7 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64):
         T.fill_noise(d_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes], T.frame_seed(k))
     d_out = torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    o = O.Oracle(ctx, threads=4)
+    o = O.Oracle(ctx, threads=threads)
     with T.VideoFrameTransform(ctx) as t:
         for idx, k in ((0, 0), (1, 1)):
             d = (*lin.dims[k], *lout.dims[k])
@@ -235,18 +237,46 @@ def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
     _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0, interpolation_alg=interp), n=2, extra_pad=40)
 
 
-# every tuning / experiment switch of the tiled kernel must leave the pixels alone
-@pytest.mark.parametrize("env", [
-    {"T360_VARIANT": "0"}, {"T360_VARIANT": "4"}, {"T360_VARIANT": "5"}, {"T360_VARIANT": "9"}, {"T360_VARIANT": "17"},
-    {"T360_STRIPS": "1"}, {"T360_PAD": "0"}, {"T360_PAD": "2"}, {"T360_PAD": "3"}, {"T360_NO_DMA": "1"},
-    {"T360_LOADERS": "2"}, {"T360_FRAMES_PER_BLOCK": "2"}, {"T360_RING_KB": "24"}, {"T360_RING_KB": "80"},
-    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"}, {"T360_WIDE64": "0"}, {"T360_WIDE64": "1000"}, {"T360_BAND": "1"},
-], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_kernel_variants_are_bit_identical(env, T, oracle_mod, monkeypatch):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    ov = dict(num_vertical_segments=5, num_horizontal_segments=4) if "LOWPASS" in "".join(env) else dict(enable_low_pass_filter=0)
-    _batch_case(T, oracle_mod, ov, n=5, extra_pad=0)
+# The shipped library reads no environment.  The instrumented build (make instr: -DT360_INSTRUMENT) does, for A/B
+# runs of ring geometries and plan options; every one of those switches must leave the pixels alone.  It is a second
+# library, so it runs in a child process (tests/run_variants.py) with T360_LIB pointing at it.
+VARIANTS = [
+    {"T360_RING_SLOTS": "3"}, {"T360_MAX_PIECES": "6", "T360_RING_SLOTS": "3"}, {"T360_MAX_PIECES": "12"},
+    {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"}, {"T360_WIDE64": "1000"}, {"T360_BAND": "1"},
+    {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"}, {"T360_FRAMES_PER_BLOCK": "3", "T360_RING_SLOTS": "3"},
+    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+]
+
+
+def test_instrumented_build_variants_are_bit_identical():
+    import json
+    import subprocess
+    import sys
+    from transform360_amd import _lib
+    instr = os.path.join(os.path.dirname(_lib.LIB_PATH), "libTransform360_instr.so")
+    assert os.path.exists(instr), "build it with `make -C transform360_amd/csrc instr`"
+    env = dict(os.environ, T360_LIB=instr)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_variants.py"), json.dumps(VARIANTS)],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert "variants ok: %d" % len(VARIANTS) in r.stdout
+
+
+def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
+    from transform360_amd import _lib
+    assert _lib.load().T360_buildFlags() == 0
+    # a switch of the instrumented build must be inert here: same kernel instantiation as without it
+    monkeypatch.setenv("T360_RING_SLOTS", "3")
+    monkeypatch.setenv("T360_NO_TILED", "1")
+    import torch
+    with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
+        assert t.generateMapForPlane(960, 480, 384, 256, 0)
+        src = torch.zeros((480, 960), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
+        _ready()
+        assert t.transformFramePlane(src, dst, 0)
+        assert t.lastKernel() == "remap_tiled_kernel<4, 8, 2>"
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)
@@ -287,6 +317,73 @@ def test_config4_lanczos_tb_full_size(T, oracle_mod):
     from tests.cases import TB
     _full_size_case(T, oracle_mod, dict(interpolation_alg=LANCZOS4, enable_low_pass_filter=0, **TB),
                     (7680, 3840, 3072, 4096))
+
+
+# ---------------------------------------------------------------- the benchmarked path itself
+# bench.py's step is ONE T360_transformFrames call over a batch of full-size yuv420p frames (Y, U and V fused into
+# one launch; 16 frames per workgroup; the 4K tile plan).  Same call here, with batches that cross the
+# frames-per-workgroup boundary, every plane of every frame against per-plane oracle calls.
+def _threads():
+    return max(4, min(32, os.cpu_count() or 4))
+
+
+def test_config2_batch_full_size_all_planes(T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, enable_low_pass_filter=0), n=19,
+                dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
+
+
+def test_config3_batch_full_size_all_planes(T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32,
+                                    adjust_kernel=1, enable_multi_threading=1), n=17,
+                dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
+
+
+def test_config1_batch_full_size_all_planes(T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(interpolation_alg=NEAREST, enable_low_pass_filter=0), n=33,
+                dims=(1920, 960, 768, 512), extra_pad=0, threads=_threads())
+
+
+def test_config4_batch_full_size_all_planes(T, oracle_mod):
+    from tests.cases import TB
+    _batch_case(T, oracle_mod, dict(interpolation_alg=LANCZOS4, enable_low_pass_filter=0, **TB), n=2,
+                dims=(7680, 3840, 3072, 4096), extra_pad=0, threads=_threads())
+
+
+def test_bilinear_batch_full_size_all_planes(T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(interpolation_alg=LINEAR, enable_low_pass_filter=0), n=17,
+                dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
+
+
+def test_five_planes_in_one_call(T, oracle_mod):
+    """More planes than one fused launch holds (4): the batch is flushed in groups."""
+    import torch
+    in_w, in_h, out_w, out_h = 960, 480, 384, 256
+    for interp in (CUBIC, LINEAR):
+        ctx = filter_defaults(interpolation_alg=interp, enable_low_pass_filter=0)
+        o = oracle_mod.Oracle(ctx, threads=4)
+        n_planes, n_frames = 5, 3
+        in_plane, out_plane = in_w * in_h, out_w * out_h
+        d_in = torch.empty(n_frames * n_planes * in_plane, dtype=torch.uint8, device="cuda")
+        T.fill_noise(d_in, 0x5EED)
+        d_out = torch.zeros(n_frames * n_planes * out_plane, dtype=torch.uint8, device="cuda")
+        from transform360_amd import _lib
+        descs = (_lib.T360PlaneDesc * n_planes)()
+        for k in range(n_planes):
+            descs[k] = _lib.T360PlaneDesc(in_offset=k * in_plane, out_offset=k * out_plane, in_stride=in_w, out_stride=out_w,
+                                          in_width=in_w, in_height=in_h, out_width=out_w, out_height=out_h, map_index=0)
+        with T.VideoFrameTransform(ctx) as t:
+            assert t.generateMapForPlane(in_w, in_h, out_w, out_h, 0) and o.generateMapForPlane(in_w, in_h, out_w, out_h, 0)
+            assert t.setStream(torch.cuda.current_stream())
+            assert t.transformFrames(d_in, n_planes * in_plane, d_out, n_planes * out_plane, n_frames, descs)
+            assert t.synchronize()
+        h_in, h_out = d_in.cpu().numpy(), d_out.cpu().numpy()
+        for f in range(n_frames):
+            for k in range(n_planes):
+                src = h_in[(f * n_planes + k) * in_plane:][:in_plane].reshape(in_h, in_w)
+                want = np.zeros((out_h, out_w), np.uint8)
+                assert o.transformFramePlane(src, want, 0, k)
+                got = h_out[(f * n_planes + k) * out_plane:][:out_plane].reshape(out_h, out_w)
+                assert np.array_equal(got, want), (interp, f, k)
 
 
 # ---------------------------------------------------------------- size-independent properties

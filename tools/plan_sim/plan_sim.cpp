@@ -1,0 +1,30 @@
+// tools/plan_sim/plan_sim.cpp -- the product's gather planner (transform360_amd/csrc/t360_plan.cpp) built
+// for the host, so that tile shapes, fetched bytes and modelled LDS bank conflicts can be compared offline
+// (tools/plan_sim/plan_sim.py feeds it the oracle's LUT).  Development tool, not part of the library.
+#include <cstdio>
+#include <cstring>
+
+#include "t360_plan.h"
+
+extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces,
+                             int wide_pct, int strip_pct, int row_pad, int unused, long long* stats /*[80]*/) {
+  t360::PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces;
+  o.wide_pct = wide_pct;
+  o.strip_pct = strip_pct;
+  o.row_pad = row_pad;
+  (void)unused;
+  o.model_stats = true;
+  t360::HostGatherPlan plan;
+  if (!t360::plan_gather(lut, dw, dh, sw, sh, o, &plan)) return 0;
+  const t360::PlanStats& s = plan.stats;
+  stats[0] = s.n_strip; stats[1] = s.n_wide; stats[2] = s.n_sq; stats[3] = s.n_16; stats[4] = s.n_direct;
+  stats[5] = s.fetched_bytes; stats[6] = s.lds_bytes; stats[7] = s.direct_pixels; stats[8] = s.lds_cycles_model;
+  stats[9] = (long long)plan.chunks.size() * 4; stats[10] = (long long)plan.tlut.size() * 4;
+  int maxp = 0;
+  for (int i = 0; i < plan.ntiles; i++) maxp = plan.tiles[i].pieces > maxp ? plan.tiles[i].pieces : maxp;
+  stats[11] = maxp;
+  for (int i = 0; i < 33; i++) stats[12 + i] = s.pieces_hist[i];
+  return 1;
+}

@@ -24,7 +24,7 @@ REFERENCE_SYMBOLS = (
 ADDITIVE_SYMBOLS = (
     "T360_version", "T360_deviceCount", "T360_setStream", "T360_useOwnStream", "T360_synchronize", "T360_transformFrames",
     "T360_filterPlane", "T360_getMapSize", "T360_copyMap", "T360_getSegmentCount", "T360_getSegment",
-    "T360_copySegmentKernels", "T360_fillNoise",
+    "T360_copySegmentKernels", "T360_fillNoise", "T360_lastKernel", "T360_getPlanStats", "T360_buildFlags",
 )
 
 
@@ -42,7 +42,7 @@ class T360PlaneDesc(C.Structure):
 def build(verbose=False):
     """Compile the library for gfx950 with hipcc (cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", CSRC_DIR, "-j8"], stdout=out)
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-j8", "all", "instr"], stdout=out)
     return LIB_PATH
 
 
@@ -90,7 +90,11 @@ def load():
     L.T360_getSegment.argtypes = [vp, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.T360_copySegmentKernels.argtypes = [vp, i, i, vp, vp]
     L.T360_fillNoise.argtypes = [u8p, C.c_int64, C.c_uint64, vp]
+    L.T360_lastKernel.argtypes = [vp]
+    L.T360_getPlanStats.argtypes = [vp, i, C.POINTER(C.c_int64)]
+    L.T360_buildFlags.argtypes = []
     for name in ADDITIVE_SYMBOLS[1:]:
         getattr(L, name).restype = i
+    L.T360_lastKernel.restype = C.c_char_p
     _lib = L
     return L

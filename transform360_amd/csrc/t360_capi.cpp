@@ -144,6 +144,21 @@ T360_EXPORT int T360_copySegmentKernels(VideoFrameTransform* t, int map_index, i
   return t->copySegmentKernels(map_index, i, kx, ky) ? 1 : 0;
 }
 
+T360_EXPORT const char* T360_lastKernel(VideoFrameTransform* t) { return t ? t->lastKernel() : ""; }
+
+T360_EXPORT int T360_getPlanStats(VideoFrameTransform* t, int map_index, int64_t* stats8) {
+  if (!t || !stats8) return 0;
+  return t->planStats(map_index, stats8) ? 1 : 0;
+}
+
+T360_EXPORT int T360_buildFlags(void) {
+#ifdef T360_INSTRUMENT
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 T360_EXPORT int T360_fillNoise(uint8_t* d_dst, int64_t nbytes, uint64_t seed, void* hip_stream) {
   if (!d_dst || nbytes < 0) return 0;
   hipError_t e = t360::launch_fill_noise(d_dst, nbytes, seed, static_cast<hipStream_t>(hip_stream));

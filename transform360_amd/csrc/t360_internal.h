@@ -77,45 +77,58 @@ struct LowpassTile {
   int x0, y0, w, h;  // absolute plane coordinates (stereo eye offset already applied)
 };
 
-// ---- LDS-tiled gather (t360_remap_tiled.hip) ----
-// Tile kinds of the work list.
+// ---- LDS-tiled gather (t360_remap_tiled.hip, planned by t360_plan.cpp) ----
+// Tile kinds of the work list.  A staged tile is 256 lanes x NPX pixels: lane = (column, band of 4 rows).
 enum : int {
-  kTileStaged32 = 0,  // 32x32 output px, 4 px per lane, source box staged through LDS
-  kTileStrip128 = 3,  // 128x8 output px, 4 px per lane: ~330-byte source row fragments, which the
-                      // memory system streams at ~6 TB/s where 96-byte fragments reach ~3 TB/s
-                      // (tools/ubench/fragment_bw.hip)
-  kTileWide64 = 4,    // 64x16 output px, 4 px per lane (lane = column, 4 bands of 4 rows): same pixels per
-                      // workgroup as a 32x32 tile with half the horizontal box borders (halo + 16-byte alignment
-                      // cost ~29 bytes per ~60-byte row of a 32x32 tile, the 3 halo rows only ~10 % of its height)
-  kTileStaged16 = 1,  // 16x16 output px, 1 px per lane, source box staged through LDS
-  kTileDirect16 = 2,  // 16x16 output px, gathers straight from global memory (box too large)
+  kTileStaged32 = 0,  // 32x32 output px, 4 px per lane (8 bands)
+  kTileStaged16 = 1,  // 16x16 output px, 1 px per lane (near the poles, where wider tiles do not fit the LDS)
+  kTileDirect16 = 2,  // 16x16 output px gathered straight from global memory (the ~4 tiles around each pole whose
+                      // source footprint spans a quadrant of longitudes)
+  kTileStrip128 = 3,  // 128x8 output px, 4 px per lane (2 bands): ~330-byte source row fragments
+  kTileWide64 = 4,    // 64x16 output px, 4 px per lane (4 bands)
 };
 enum : int {
   kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
-  kTileSeamShift = 2,  // box x coordinates use (x >= W/2 ? x - W : x)
+  kTileSeamShift = 2,  // staged x coordinates use (x >= W/2 ? x - W : x): the tile straddles the +-180 degree seam
 };
 
-constexpr int kStageChunk = 16;                 // bytes per staged chunk (one dwordx4 per lane)
-constexpr int kStageChunksPerLane = 4;          // max chunks a lane fetches per frame
-constexpr int kStageMaxBytes = 256 * kStageChunksPerLane * kStageChunk;  // 16 KiB box per tile
-constexpr int kStageMaxCols = 1024;             // 10-bit box column in the tile LUT word
-constexpr int kStageMaxRows = 256;              // 8-bit box row
+constexpr int kStageChunk = 16;   // bytes per staged chunk (one dwordx4 per DMA lane)
+constexpr int kPieceChunks = 64;  // chunks per DMA instruction (one per lane): a 1 KiB "piece"
+constexpr int kMaxPieces = 16;    // pieces per copy of a tile's staged region (the loader keeps 16 offsets per lane)
 
-// One unit of gather work.
+// One unit of gather work.  The staged region of a tile is NOT a bounding box: the planner lists exactly the
+// 16-byte source chunks the tile's stencils touch (the footprint of an output tile in the equirect source is a
+// curved band, on the polar faces an annular sector) and packs the box rows back to back in LDS: row r occupies
+// chunk positions row_pos[r] .. row_pos[r] + len[r] - 1.  Every pixel carries the LDS address of each of its
+// stencil rows, so rows need no common pitch and HBM only delivers bytes that are used.
 struct __attribute__((aligned(16))) TileDesc {
   int16_t ox, oy;     // output origin
   int16_t kind;       // kTile*
   int16_t flags;      // kTilePartial | kTileSeamShift
-  int32_t x0, y0;     // source box origin incl. stencil halo; x0 is a multiple of 16 (may be < 0)
-  int16_t cpr;        // 16-byte chunks per box row (row pitch in LDS = cpr * 16 bytes)
-  int16_t rows;       // box rows
-  int32_t tlut;       // first word of this tile in the box-relative LUT
-  int16_t cpr_src;    // chunks per row that hold source bytes; columns cpr_src..cpr-1 are LDS padding that
-                      // moves consecutive rows onto different banks (their lanes re-read chunk 0)
-  int16_t pad16;
-  int32_t pad;
+  int32_t tlut;       // first pixel word of this tile (lane order)
+  int32_t chunks;     // first entry of the tile's chunk table: 64 * pieces entries (chunk_entry()), followed by
+                      // the row table (2 int16 per dword)
+  int16_t pieces;     // 1 KiB DMA pieces per copy of the staged region
+  int16_t rows;       // box rows (entries of the row table)
+  int32_t fetched;    // distinct source chunks among the positions (statistics)
+  int32_t pad[2];
 };
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
+
+// Pixel word of a staged tile:
+//   bits 0..10   x of the stencil's left tap relative to the box origin (byte units, < 2048)
+//   bits 11..18  box row of the stencil's top tap (< 256)
+//   bits 19..28  sub-pixel phase
+//   bit 31       pixel outside the plane (partial tile)
+// LDS byte offset of the tap at stencil row k = row_base[row + k] * 16 + x, with the tile's row table
+// (int16 per box row, in 16-byte chunks: LDS position of the row minus its first staged column) stored behind
+// the tile's chunk table.
+constexpr uint32_t kWordDead = 0x80000000u;
+constexpr int kWordRowShift = 11, kWordFracShift = 19;
+constexpr int kBoxMaxCols = 2048 / 16;  // chunk columns of a box
+constexpr int kBoxMaxRows = 256;
+// Chunk table entry: source row (already wrapped) and 16-byte column (already wrapped) of one LDS position.
+inline uint32_t chunk_entry(uint32_t sy, uint32_t cx) { return (sy << 12) | cx; }
 
 // Bicubic weights re-packed for v_dot4: per phase 12 dwords
 //   [0..3]  high bytes (signed)  of the 4 taps of rows 0..3:  w >> 8

@@ -30,14 +30,7 @@ hipError_t launch_remap_gather(const GatherArgs& a, int nframes, hipStream_t str
 hipError_t launch_fill_plane(uint8_t* dst, int64_t frame_bytes, int w, int h, int stride, int value,
                              int nframes, hipStream_t stream);
 
-// ---- tile planning (t360_tiles.hip) ----
-// out: kScanBoxes*6 ints per 128x32 macro region ({minx, maxx, minx_shifted, maxx_shifted, miny, maxy} per box)
-constexpr int kScanBoxes = 24;
-hipError_t launch_tile_scan(const LutEntry* lut, int dw, int dh, int sw, int* out, hipStream_t stream);
-hipError_t launch_tile_lut(const LutEntry* lut, int dw, int dh, int sw, const TileDesc* tiles, int ntiles,
-                           int halo, uint32_t* tlut, hipStream_t stream);
-
-// ---- LDS-tiled bicubic gather (t360_remap_tiled.hip) ----
+// ---- LDS-tiled gather (t360_remap_tiled.hip; work list planned by t360_plan.cpp) ----
 struct TiledPlane {
   const uint8_t* src;       // plane base of frame 0
   int64_t src_frame_bytes;  // distance between consecutive frames of this plane
@@ -45,38 +38,33 @@ struct TiledPlane {
   int64_t dst_frame_bytes;
   int sw, sh, sstride;
   int dw, dh, dstride;
-  const TileDesc* tiles;
-  const uint32_t* tlut;     // box-relative LUT words
+  const TileDesc* tiles;    // ntiles staged tiles, then ndirect direct tiles
+  const uint32_t* tlut;     // pixel words of the staged tiles
+  const uint32_t* chunks;   // chunk tables + row tables of the staged tiles
   const LutEntry* lut;      // absolute LUT (direct tiles)
   int ntiles;
+  int ndirect;
   int dst_dword_ok;         // plane base, stride and frame distance are 4-byte aligned: dword stores
-  int src_vec_ok;           // ... 16-byte aligned and sw % 16 == 0: every staged chunk is one dwordx4
-  int ndirect;              // kTileDirect16 descriptors stored behind the ntiles staged ones
 };
 struct TiledArgs {
   const int16_t* wtab;      // OpenCV Q15 table (direct tiles)
   const uint32_t* wpack;    // pack_dwords(ks) per phase (staged tiles)
   int ks;                   // taps per axis of the interpolation: 1, 2, 4 (bicubic) or 8
   int nframes;
-  int frames_per_block;
+  int frames_per_block;     // frames one workgroup walks with its tile
   int nplanes;
-  int total_tiles;
-  int ring_bytes;           // LDS ring of the DMA-staged kernel
-  int loader_waves;         // DMA loader waves per workgroup (1..4) next to the 4 consumer waves
-  int debug;                // experiments (T360_DEBUG): bit2 no steady-state DMA, bit3 no gather
-  int variant;              // DMA kernel build: bit0 LDS reads in groups of 2 px, bit2 no loader wave,
-                            // bit3 persistent workgroups, bit4 LDS flags instead of the frame barrier
-  unsigned long long* trace;  // optional: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
-  int* work_counters;       // persistent variant (bit3): 8 zeroed ints, one item queue per XCD
-  int persist_slots;        // persistent variant: workgroups to launch (resident slots of the device)
+  int total_tiles;          // staged tiles of all planes
+  int total_direct;         // direct tiles of all planes
+  int direct_blocks;        // total_direct rounded up to a multiple of 8 (keeps blockIdx.x % 8 = XCD for the rest)
+  int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces): selects the ring geometry
+  int ring_slots;           // frames in flight per workgroup (2 or 3)
   TiledPlane plane[4];
 };
-// Fused launch over all planes; every plane must have src_vec_ok (chunks go global -> LDS by DMA).
-hipError_t launch_remap_tiled_cubic_dma(const TiledArgs& a, hipStream_t stream);
-// Direct (unstaged) tiles of all planes in `a` (plane[k].tiles + ntiles, ndirect of them): one launch.
-hipError_t launch_remap_direct_cubic(const TiledArgs& a, hipStream_t stream);
-// One plane, chunks staged through registers (any alignment / width).
-hipError_t launch_remap_tiled_cubic_regs(const TiledArgs& a, hipStream_t stream);
+// One launch for all planes of a batch (<= 4): staged tiles by LDS-DMA, pole tiles gathered directly.
+// Every plane's source must be 16-byte friendly (base, stride, frame distance, width).
+hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream);
+// the instantiation launch_remap_tiled() picks for these parameters (reporting)
+const char* remap_tiled_kernel_name(int ks, int max_pieces, int ring_slots);
 
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {

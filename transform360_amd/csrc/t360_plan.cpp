@@ -1,249 +1,394 @@
-// t360_plan.cpp -- init-time planning of the LDS-tiled gather (host side).
+// t360_plan.cpp -- init-time planning of the LDS-tiled gather (host side, no HIP).
 //
-// From the scanned per-tile bounding boxes (tile_scan_kernel) build the tile work list:
-//   32x32 output tile  -> staged through LDS when its source box (incl. stencil halo, x aligned
-//                         down to 16 bytes) fits the per-workgroup staging budget;
-//   otherwise its four 16x16 quadrants, each staged if it fits, else gathered directly
-//                         (the few tiles touching a pole span a full quadrant of longitudes,
-//                         SURVEY.md 7 H4).
-// Tiles are emitted in output raster order; the kernel hands contiguous ranges to each XCD.
+// The output plane is cut into tiles of 256 lanes x NPX pixels (128x8, 64x16 or 32x32 px with 4 px per lane;
+// 16x16 px with 1 px per lane near the poles).  For every tile the planner derives from the sample LUT
+//   * the FOOTPRINT: the set of 16-byte source chunks the tile's stencils touch.  In the equirect source the
+//     footprint of a cube-face tile is a curved band (an annular sector on the polar faces); its bounding box
+//     would stage up to 2.6x the bytes that are used, so the footprint is kept exact, row by row;
+//   * an LDS placement: the box rows are packed back to back (row r holds the chunks first[r] .. last[r] of its
+//     source row at LDS chunk positions pos[r] ..), so LDS and DMA lanes carry almost no holes either;
+//   * the chunk table the loader wave walks: per LDS position the source (row, 16-byte column), with the
+//     +-180 degree seam and BORDER_WRAP across the poles already resolved; positions nobody needs repeat
+//     their predecessor's source chunk (an L1 hit, no HBM traffic);
+//   * the pixel words in the lane order of the gather (box row and x of the stencil's top-left tap, phase) and the
+//     row table that turns a box row into an LDS address (rows have no common pitch).
+// Tiles whose footprint exceeds the staging budget even at 16x16 (the ~4 tiles around each pole)
+// are listed as direct tiles.  Tiles are emitted in execution order; the kernel hands contiguous ranges of the
+// list to each XCD so that neighbouring tiles -- whose footprints share the stencil halo -- share an L2.
 #include "t360_plan.h"
 
 #include <algorithm>
-#include <cstdio>
 #include <cstdlib>
-#include <vector>
+#include <cstring>
 
 namespace t360 {
 
 namespace {
 
-struct Box {
-  int x0, cpr, y0, rows;
-  bool seam_shift;
-  bool empty;
-  bool fits;
+struct TileShape {
+  int kind, w, h, npx;
 };
+constexpr TileShape kStrip{kTileStrip128, 128, 8, 4};
+constexpr TileShape kWide{kTileWide64, 64, 16, 4};
+constexpr TileShape kSquare{kTileStaged32, 32, 32, 4};
+constexpr TileShape kSmall{kTileStaged16, 16, 16, 1};
 
-// b: {minx, maxx, minx_shifted, maxx_shifted, miny, maxy} of pixel-centre taps
-Box make_box(const int* b, int halo_lo, int halo_hi, int max_chunks) {
-  Box r{};
-  r.empty = b[0] > b[1];
-  if (r.empty) return r;
-  const int w_raw = b[1] - b[0], w_shift = b[3] - b[2];
-  r.seam_shift = w_shift < w_raw;
-  const int xmin = (r.seam_shift ? b[2] : b[0]) - halo_lo;
-  const int xmax = (r.seam_shift ? b[3] : b[1]) + halo_hi;
-  r.x0 = xmin & ~(kStageChunk - 1);  // two's complement: floors negatives too
-  r.cpr = (xmax - r.x0) / kStageChunk + 1;
-  r.y0 = b[4] - halo_lo;
-  r.rows = (b[5] + halo_hi) - r.y0 + 1;
-  r.fits = r.cpr * kStageChunk <= kStageMaxCols && r.rows <= kStageMaxRows &&
-           r.cpr * r.rows <= max_chunks;
-  return r;
+inline int floor_div16(int v) { return v >> 4; }  // arithmetic shift: floors negatives too
+inline int wrap(int v, int n) {
+  v %= n;
+  return v < 0 ? v + n : v;
 }
 
-}  // namespace
+// Footprint and LDS placement of one candidate tile.
+struct Foot {
+  bool empty = true;      // no pixel inside the plane
+  bool feasible = false;  // fits the staging budget
+  bool seam = false;
+  int ox = 0, oy = 0;
+  TileShape shape{};
+  int y0 = 0, rows = 0;   // box rows: source rows y0 .. y0 + rows - 1 (before wrapping)
+  int c0 = 0, ncols = 0;  // box chunk columns c0 .. c0 + ncols - 1 (seam-shifted coordinates, may be negative)
+  std::vector<uint8_t> mask;  // rows x ncols: chunk is part of the footprint
+  std::vector<int> first, last, pos;  // per box row: marked chunk columns first..last (-1: none), LDS chunk position
+  int npos = 0;           // LDS chunk positions
+  int pieces = 0;
+  int fetched = 0;        // marked chunks
+};
 
-bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, int max_box_bytes,
-                       hipStream_t stream, GatherPlan* plan) {
-  plan->valid = false;
-  plan->ntiles = 0;
-  if (!(ksize == 1 || ksize == 2 || ksize == 4 || ksize == 8)) return true;
-  // taps of a ksize-wide stencil around the LUT's integer coordinate: -(ksize/2-1) .. +ksize/2
-  // (nearest: the pixel itself)
-  const int halo_lo = ksize == 1 ? 0 : ksize / 2 - 1, halo_hi = ksize == 1 ? 0 : ksize / 2;
-  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane, 16x16 tiles only
-  const bool only16 = ksize == 8;
-  int max_chunks = max_box_bytes / kStageChunk;
-  if (max_chunks > 256 * kStageChunksPerLane) max_chunks = 256 * kStageChunksPerLane;
-  const int regions_x = (dw + 127) / 128, regions_y = (dh + 31) / 32;
-  const size_t nregions = (size_t)regions_x * regions_y;
-  const int per_region = kScanBoxes * 6;
+class Planner {
+ public:
+  Planner(const LutEntry* lut, int dw, int dh, int sw, int sh, const PlanOptions& opt)
+      : lut_(lut), dw_(dw), dh_(dh), sw_(sw), sh_(sh), opt_(opt) {
+    lo_ = opt.ks == 1 ? 0 : opt.ks / 2 - 1;  // taps of a ks-wide stencil: -(ks/2-1) .. +ks/2 around the LUT's
+    hi_ = opt.ks == 1 ? 0 : opt.ks / 2;      // integer coordinate (nearest: the pixel itself)
+    max_pos_ = std::min(opt.max_pieces, kMaxPieces) * kPieceChunks;
+  }
 
-  DeviceBuffer scan;
-  if (!scan.reserve(nregions * per_region * sizeof(int))) return false;
-  if (launch_tile_scan(d_lut, dw, dh, sw, scan.as<int>(), stream) != hipSuccess) return false;
-  std::vector<int> boxes(nregions * per_region);
-  if (hipMemcpyAsync(boxes.data(), scan.as<void>(), boxes.size() * sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
-    return false;
-  if (hipStreamSynchronize(stream) != hipSuccess) return false;
-
-  std::vector<TileDesc> tiles, direct;
-  tiles.reserve(nregions * 4);
-  int64_t tlut_words = 0, staged_bytes = 0;
-  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0, nwide = 0;
-  // 128x8 strips give ~330-byte row fragments (better for HBM) but measured ~4 % slower end to end
-  // while the kernel is VALU-issue-bound; opt-in until that changes (DESIGN.md, round-1 notes)
-  // 64x16 tiles replace pairs of 32x32 tiles unless they would stage more than wide_pct % of the pair's
-  // bytes (T360_WIDE64=0 turns them off).  Measured on config 2: 6-7 % faster end to end at 150-1000 %
-  // although more bytes go through LDS -- the ~160-byte row fragments and the halved number of
-  // horizontal box borders are what the fabric and HBM see.
-  const int wide_pct = getenv("T360_WIDE64") ? atoi(getenv("T360_WIDE64")) : 200;
-  const bool wide64 = wide_pct > 0 && (ksize == 2 || ksize == 4);  // nearest has no halo to save, Lanczos4 is 16x16 only
-  const int strips_mode = getenv("T360_STRIPS") ? atoi(getenv("T360_STRIPS")) : 0;  // 2: wherever a strip fits (experiment)
-  const bool allow_strips = strips_mode > 0;
-  const int pad_mode = getenv("T360_PAD") ? atoi(getenv("T360_PAD")) : 1;
-  int cpr_hist[64] = {0};
-  auto emit = [&](const Box& bx, int kind, int tox, int toy, int ew, int eh) {
-    TileDesc t{};
-    t.ox = (int16_t)tox;
-    t.oy = (int16_t)toy;
-    t.kind = (int16_t)kind;
-    t.flags = (int16_t)((bx.seam_shift ? kTileSeamShift : 0) | ((tox + ew > dw || toy + eh > dh) ? kTilePartial : 0));
-    t.x0 = bx.x0;
-    t.y0 = bx.y0;
-    int cpr = bx.cpr;
-    if (pad_mode && kind != kTileDirect16) {
-      // LDS row pitch = 16*cpr bytes = 4*cpr banks.  The lanes of one output row drift over 2-3 source
-      // rows; with a pitch near a multiple of 128 bytes those rows land on the same banks (57 % of
-      // the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).  Padding columns (never fetched
-      // from HBM) put consecutive rows 8..24 banks apart.
-      int want = cpr;
-      if (pad_mode == 1)
-        while ((want & 7) == 7 || (want & 7) == 0 || (want & 7) == 1) want++;
-      else if (pad_mode == 2)
-        while ((want & 7) != 4) want++;
-      else
-        while ((want & 7) < 3 || (want & 7) > 5) want++;
-      if ((int64_t)want * bx.rows <= (int64_t)max_chunks && want * kStageChunk <= kStageMaxCols) cpr = want;
+  void footprint(int ox, int oy, const TileShape& shape, Foot* f) const {
+    f->empty = true;
+    f->feasible = false;
+    f->ox = ox;
+    f->oy = oy;
+    f->shape = shape;
+    const int x1 = std::min(ox + shape.w, dw_), y1 = std::min(oy + shape.h, dh_);
+    if (ox >= dw_ || oy >= dh_) return;
+    int minx = 1 << 30, maxx = -(1 << 30), mins = 1 << 30, maxs = -(1 << 30), miny = 1 << 30, maxy = -(1 << 30);
+    for (int y = oy; y < y1; y++) {
+      const LutEntry* row = lut_ + (size_t)y * dw_;
+      for (int x = ox; x < x1; x++) {
+        const int sx = row[x].ix, sy = row[x].iy;
+        const int ss = sx >= (sw_ >> 1) ? sx - sw_ : sx;
+        minx = std::min(minx, sx); maxx = std::max(maxx, sx);
+        mins = std::min(mins, ss); maxs = std::max(maxs, ss);
+        miny = std::min(miny, sy); maxy = std::max(maxy, sy);
+      }
     }
-    cpr_hist[cpr < 64 ? cpr : 63]++;
-    t.cpr = (int16_t)cpr;
-    t.cpr_src = (int16_t)bx.cpr;
-    t.rows = (int16_t)bx.rows;
-    t.tlut = (int32_t)tlut_words;
-    if (kind == kTileDirect16) {
-      ndirect++;
-      direct.push_back(t);
+    f->empty = false;
+    f->seam = (maxs - mins) < (maxx - minx);
+    const int xa = (f->seam ? mins : minx) - lo_, xb = (f->seam ? maxs : maxx) + hi_;
+    f->c0 = floor_div16(xa);
+    f->ncols = floor_div16(xb) - f->c0 + 1;
+    f->y0 = miny - lo_;
+    f->rows = maxy + hi_ - f->y0 + 1;
+    // a footprint wider than the plane or taller than what 16 pieces hold cannot be staged
+    if (f->ncols * kStageChunk > sw_ || f->ncols > kBoxMaxCols || f->rows > kBoxMaxRows || f->rows > max_pos_) return;
+    f->mask.assign((size_t)f->rows * f->ncols, 0);
+    int fetched = 0;
+    for (int y = oy; y < y1; y++) {
+      const LutEntry* row = lut_ + (size_t)y * dw_;
+      for (int x = ox; x < x1; x++) {
+        int sx = row[x].ix;
+        if (f->seam && sx >= (sw_ >> 1)) sx -= sw_;
+        const int ca = floor_div16(sx - lo_) - f->c0, cb = floor_div16(sx + hi_) - f->c0;
+        const int r0 = row[x].iy - lo_ - f->y0;
+        for (int r = r0; r < r0 + opt_.ks; r++) {
+          uint8_t* m = &f->mask[(size_t)r * f->ncols];
+          for (int c = ca; c <= cb; c++) {
+            fetched += m[c] == 0;
+            m[c] = 1;
+          }
+        }
+      }
+    }
+    f->fetched = fetched;
+    if (fetched > max_pos_) return;
+    place(f);
+  }
+
+  // rows back to back
+  void place(Foot* f) const {
+    f->first.assign((size_t)f->rows, -1);
+    f->last.assign((size_t)f->rows, -1);
+    f->pos.assign((size_t)f->rows, 0);
+    int at = 0;
+    for (int r = 0; r < f->rows; r++) {
+      const uint8_t* m = &f->mask[(size_t)r * f->ncols];
+      for (int c = 0; c < f->ncols; c++)
+        if (m[c]) {
+          if (f->first[(size_t)r] < 0) f->first[(size_t)r] = c;
+          f->last[(size_t)r] = c;
+        }
+      f->pos[(size_t)r] = at;
+      if (f->first[(size_t)r] >= 0) at += f->last[(size_t)r] - f->first[(size_t)r] + 1 + row_pad(*f, r);
+    }
+    f->npos = at;
+    f->pieces = (at + kPieceChunks - 1) / kPieceChunks;
+    if (at <= 0 || at > max_pos_) return;
+    f->feasible = true;
+  }
+
+  // optional padding chunks behind a row (LDS bank spreading, PlanOptions::row_pad)
+  int row_pad(const Foot& f, int r) const {
+    if (opt_.row_pad <= 0) return 0;
+    const int len = f.last[(size_t)r] - f.first[(size_t)r] + 1;
+    // make (len + pad) odd multiples that avoid 0 mod 8: rows then start on different 128-byte bank halves
+    int pad = 0;
+    while (pad < opt_.row_pad && ((len + pad) & 7) == 0) pad++;
+    return pad;
+  }
+
+  // LDS chunk-granular address term of box row r: byte offset of source x (seam-shifted, minus the box origin)
+  // in row r is row_base(r) * 16 + (x - c0 * 16)
+  int row_base(const Foot& f, int r) const { return f.pos[(size_t)r] - f.first[(size_t)r]; }
+
+  // LDS byte offset (inside one copy) of the tap at stencil row k of the pixel with LUT entry e
+  int tap_offset(const Foot& f, const LutEntry& e, int k) const {
+    int sx = e.ix;
+    if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
+    const int r = e.iy - lo_ - f.y0 + k;
+    return row_base(f, r) * kStageChunk + (sx - lo_ - f.c0 * kStageChunk);
+  }
+
+  // Modelled LDS cycles of the tile's ds_read_b64 reads (MI355X_MICROARCH.md "LDS": two 32-lane groups per
+  // instruction, bank = dword address % 64, cycles of a group = most distinct addresses on one bank; checked on
+  // these patterns by tools/ubench/lds_patterns.hip).  Summed over the stencil rows.
+  int lds_cycles(const Foot& f) const {
+    const int bbase = (1 << 20) + 4;  // copy B starts at a multiple of 1 KiB plus 4: only (address % 256) matters here
+    const TileShape& s = f.shape;
+    int total = 0;
+    const int npx = s.npx;
+    for (int g = 0; g < 8; g++) {  // 8 groups of 32 lanes
+      for (int p = 0; p < npx; p++)
+        for (int k = 0; k < opt_.ks; k++) {
+          int cnt[64];
+          int addr_of[64][4];
+          memset(cnt, 0, sizeof(cnt));
+          int worst = 1;
+          for (int l = 0; l < 32; l++) {
+            const int tid = g * 32 + l;
+            int px, py;
+            if (npx == 4) {
+              px = f.ox + tid % s.w;
+              py = f.oy + (tid / s.w) * 4 + p;
+            } else {
+              px = f.ox + (tid & 15);
+              py = f.oy + (tid >> 4);
+            }
+            if (px >= dw_ || py >= dh_) continue;
+            const int off = tap_offset(f, lut_[(size_t)py * dw_ + px], k);
+            const int a = (off & ~3) + ((off & 4) ? bbase : 0);
+            for (int j = 0; j < 2; j++) {
+              const int d = (a >> 2) + j, b = d & 63;
+              bool seen = false;
+              for (int i = 0; i < cnt[b] && i < 4; i++) seen = seen || addr_of[b][i] == d;
+              if (!seen) {
+                if (cnt[b] < 4) addr_of[b][cnt[b]] = d;
+                cnt[b]++;
+                worst = std::max(worst, cnt[b]);
+              }
+            }
+          }
+          total += worst;
+        }
+    }
+    return total;
+  }
+
+  void emit(const Foot& f, HostGatherPlan* out) const {
+    TileDesc t{};
+    t.ox = (int16_t)f.ox;
+    t.oy = (int16_t)f.oy;
+    const TileShape& s = f.shape;
+    const bool partial = f.ox + s.w > dw_ || f.oy + s.h > dh_;
+    t.flags = (int16_t)((f.seam ? kTileSeamShift : 0) | (partial ? kTilePartial : 0));
+    PlanStats& st = out->stats;
+    if (!f.feasible) {
+      t.kind = kTileDirect16;
+      direct_.push_back(t);
+      st.n_direct++;
+      st.direct_pixels += (int64_t)(std::min(f.ox + s.w, dw_) - f.ox) * (std::min(f.oy + s.h, dh_) - f.oy);
       return;
     }
-    tlut_words += kind == kTileStaged16 ? 256 : 1024;
-    staged_bytes += (int64_t)cpr * kStageChunk * bx.rows;
-    (kind == kTileStaged16 ? n16 : kind == kTileStaged32 ? n32 : kind == kTileWide64 ? nwide : nstrip)++;
-    tiles.push_back(t);
-  };
-  // Emission order = execution order (each XCD gets a contiguous range).  Region rows are walked in
-  // bands of `band` rows, column by column inside a band, so that vertically adjacent tiles -- whose
-  // source boxes share the stencil halo and the rows the curved footprint adds -- run at the same time
-  // on the same XCD and meet in its L2 (+2 % measured; T360_BAND=1 is plain raster order).
-  const int band = getenv("T360_BAND") ? std::max(1, atoi(getenv("T360_BAND"))) : 4;
-  for (int ry0 = 0; ry0 < regions_y; ry0 += band)
-    for (int rx = 0; rx < regions_x; rx++)
-      for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) {
-      const int* b = &boxes[((size_t)ry * regions_x + rx) * per_region];
-      const int ox = rx * 128, oy = ry * 32;
-      // option A: four 128x8 strips (wide row fragments stream ~2x faster from HBM than the
-      // ~100-byte fragments of 32x32 tiles); option B: four 32x32 tiles with 16x16 fallback.
-      Box strip[4], tile[4];
-      bool strips_ok = allow_strips && !only16;
-      int64_t strip_bytes = 0, tile_bytes = 0;
-      for (int k = 0; k < 4; k++) {
-        strip[k] = make_box(b + 6 * k, halo_lo, halo_hi, max_chunks);
-        tile[k] = make_box(b + 6 * (4 + k), halo_lo, halo_hi, max_chunks);
-        if (only16) tile[k].fits = false;
-        if (!strip[k].empty) {
-          strips_ok = strips_ok && strip[k].fits;
-          strip_bytes += (int64_t)strip[k].cpr * kStageChunk * strip[k].rows;
+    t.kind = (int16_t)s.kind;
+    t.tlut = (int32_t)out->tlut.size();
+    t.chunks = (int32_t)out->chunks.size();
+    t.pieces = (int16_t)f.pieces;
+    t.fetched = f.fetched;
+    // chunk table: position -> source chunk; holes repeat the previous valid entry
+    const size_t base = out->chunks.size();
+    out->chunks.resize(base + (size_t)f.pieces * kPieceChunks, 0xffffffffu);
+    for (int r = 0; r < f.rows; r++) {
+      if (f.first[(size_t)r] < 0) continue;
+      const uint8_t* m = &f.mask[(size_t)r * f.ncols];
+      const int sy = wrap(f.y0 + r, sh_);
+      for (int c = f.first[(size_t)r]; c <= f.last[(size_t)r]; c++)
+        if (m[c]) {
+          const int cx = wrap((f.c0 + c) * kStageChunk, sw_) / kStageChunk;
+          out->chunks[base + (size_t)(f.pos[(size_t)r] + c - f.first[(size_t)r])] = chunk_entry((uint32_t)sy, (uint32_t)cx);
         }
-        if (!tile[k].empty) {
-          if (tile[k].fits) {
-            tile_bytes += (int64_t)tile[k].cpr * kStageChunk * tile[k].rows;
-          } else {
-            for (int qd = 0; qd < 4; qd++) {
-              const Box sub = make_box(b + 6 * (8 + 4 * k + qd), halo_lo, halo_hi, max_chunks);
-              if (!sub.empty) tile_bytes += sub.fits ? (int64_t)sub.cpr * kStageChunk * sub.rows : (int64_t)1 << 20;
+    }
+    uint32_t prev = 0xffffffffu;
+    for (size_t i = base; i < out->chunks.size() && prev == 0xffffffffu; i++) prev = out->chunks[i];
+    for (size_t i = base; i < out->chunks.size(); i++) {
+      if (out->chunks[i] == 0xffffffffu)
+        out->chunks[i] = prev;
+      else
+        prev = out->chunks[i];
+    }
+    // row table behind the chunk table
+    t.rows = (int16_t)f.rows;
+    {
+      const size_t rb = out->chunks.size();
+      out->chunks.resize(rb + (size_t)(f.rows + 1) / 2, 0);
+      for (int r = 0; r < f.rows; r++) {
+        const uint32_t v = (uint32_t)(uint16_t)(int16_t)(f.first[(size_t)r] < 0 ? 0 : row_base(f, r));
+        out->chunks[rb + (size_t)r / 2] |= v << (16 * (r & 1));
+      }
+    }
+    // pixel words, lane order of the gather
+    const int words = s.npx * 256;
+    out->tlut.resize(out->tlut.size() + (size_t)words, kWordDead);
+    uint32_t* w = &out->tlut[(size_t)t.tlut];
+    for (int tid = 0; tid < 256; tid++)
+      for (int p = 0; p < s.npx; p++) {
+        int px, py;
+        if (s.npx == 4) {
+          px = f.ox + tid % s.w;
+          py = f.oy + (tid / s.w) * 4 + p;
+        } else {
+          px = f.ox + (tid & 15);
+          py = f.oy + (tid >> 4);
+        }
+        if (px >= dw_ || py >= dh_) continue;
+        const LutEntry& e = lut_[(size_t)py * dw_ + px];
+        int sx = e.ix;
+        if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
+        const uint32_t xrel = (uint32_t)(sx - lo_ - f.c0 * kStageChunk);
+        const uint32_t r0 = (uint32_t)(e.iy - lo_ - f.y0);
+        w[tid * s.npx + p] = xrel | (r0 << kWordRowShift) | ((uint32_t)e.frac << kWordFracShift);
+      }
+    out->tiles.push_back(t);
+    st.fetched_bytes += (int64_t)f.fetched * kStageChunk;
+    st.lds_bytes += (int64_t)f.npos * kStageChunk;
+    st.pieces_hist[f.pieces < 32 ? f.pieces : 32]++;
+    if (opt_.model_stats && opt_.ks != 1) st.lds_cycles_model += lds_cycles(f);
+    (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq : st.n_16)++;
+  }
+
+  bool run(HostGatherPlan* out) const {
+    out->tiles.clear();
+    out->tlut.clear();
+    out->chunks.clear();
+    out->stats = PlanStats();
+    direct_.clear();
+    const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
+    const bool wide_ok = !only16 && opt_.wide_pct > 0 && opt_.ks != 1;  // nearest has no halo to share
+    const bool strip_ok = !only16 && opt_.strip_pct > 0;
+    const int regions_x = (dw_ + 127) / 128, regions_y = (dh_ + 31) / 32;
+    const int band = std::max(1, opt_.band);
+    // Emission order = execution order.  Region rows are walked in bands, column by column inside a band, so
+    // that vertically adjacent tiles -- whose footprints share the stencil halo and the rows a curved footprint
+    // adds -- run at the same time on the same XCD and meet in its L2.
+    Foot strip[4], wide[4], sq[4], small;
+    for (int ry0 = 0; ry0 < regions_y; ry0 += band)
+      for (int rx = 0; rx < regions_x; rx++)
+        for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) {
+          const int ox = rx * 128, oy = ry * 32;
+          // squares first (always evaluated: they are the fallback), then the wider shapes
+          auto cost_sq = [&](int k, bool* all_staged) -> int64_t {
+            if (sq[k].empty) return 0;
+            if (sq[k].feasible) return (int64_t)sq[k].fetched;
+            *all_staged = false;
+            return (int64_t)1 << 40;
+          };
+          for (int k = 0; k < 4; k++) {
+            if (only16)
+              sq[k].empty = ox + 32 * k >= dw_ || oy >= dh_, sq[k].feasible = false;
+            else
+              footprint(ox + 32 * k, oy, kSquare, &sq[k]);
+          }
+          bool strips_chosen = false;
+          if (strip_ok) {
+            bool ok = true, sq_ok = true;
+            int64_t cs = 0, cq = 0;
+            for (int k = 0; k < 4; k++) {
+              footprint(ox, oy + 8 * k, kStrip, &strip[k]);
+              if (!strip[k].empty) {
+                ok = ok && strip[k].feasible;
+                cs += strip[k].fetched;
+              }
+              cq += cost_sq(k, &sq_ok);
+            }
+            if (ok && (!sq_ok || cs * 100 <= cq * opt_.strip_pct)) {
+              for (int k = 0; k < 4; k++)
+                if (!strip[k].empty) emit(strip[k], out);
+              strips_chosen = true;
+            }
+          }
+          if (strips_chosen) continue;
+          for (int h = 0; h < 2; h++) {
+            bool done = false;
+            if (wide_ok && !sq[2 * h].empty && !sq[2 * h + 1].empty) {
+              footprint(ox + 64 * h, oy, kWide, &wide[0]);
+              footprint(ox + 64 * h, oy + 16, kWide, &wide[1]);
+              const bool wf = (wide[0].empty || wide[0].feasible) && (wide[1].empty || wide[1].feasible) && !wide[0].empty;
+              bool sq_ok = true;
+              const int64_t cq = cost_sq(2 * h, &sq_ok) + cost_sq(2 * h + 1, &sq_ok);
+              const int64_t cw = (wide[0].empty ? 0 : wide[0].fetched) + (wide[1].empty ? 0 : wide[1].fetched);
+              if (wf && (!sq_ok || cw * 100 <= cq * opt_.wide_pct)) {
+                if (!wide[0].empty) emit(wide[0], out);
+                if (!wide[1].empty) emit(wide[1], out);
+                done = true;
+              }
+            }
+            if (done) continue;
+            for (int k = 2 * h; k < 2 * h + 2; k++) {
+              if (sq[k].empty) continue;
+              if (sq[k].feasible) {
+                emit(sq[k], out);
+                continue;
+              }
+              for (int qd = 0; qd < 4; qd++) {
+                footprint(ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, kSmall, &small);
+                if (!small.empty) emit(small, out);  // staged 16x16 or direct
+              }
             }
           }
         }
-      }
-      // strips win unless they stage clearly more bytes (curved rows on the polar faces)
-      if (strips_ok && (strip_bytes * 2 <= tile_bytes * 3 || strips_mode >= 2)) {
-        for (int k = 0; k < 4; k++)
-          if (!strip[k].empty) emit(strip[k], kTileStrip128, ox, oy + 8 * k, 128, 8);
-        continue;
-      }
-      // option C: per half region (64x32 output px) two 64x16 tiles instead of two 32x32 tiles when they
-      // stage fewer bytes; their boxes are the unions of the scanned 16x16 quadrant boxes
-      bool half_done[2] = {false, false};
-      if (wide64) {
-        for (int h = 0; h < 2; h++) {
-          const Box& ta = tile[2 * h];
-          const Box& tb = tile[2 * h + 1];
-          if (ta.empty || tb.empty || !ta.fits || !tb.fits) continue;
-          Box w[2];
-          bool ok = true;
-          int64_t wide_bytes = 0;
-          for (int v = 0; v < 2 && ok; v++) {
-            int u[6] = {1 << 30, -(1 << 30), 1 << 30, -(1 << 30), 1 << 30, -(1 << 30)};
-            for (int t2 = 0; t2 < 2; t2++)
-              for (int qx = 0; qx < 2; qx++) {
-                const int* q = b + 6 * (8 + 4 * (2 * h + t2) + 2 * v + qx);
-                if (q[0] > q[1]) continue;  // empty quadrant (plane edge)
-                u[0] = std::min(u[0], q[0]); u[1] = std::max(u[1], q[1]);
-                u[2] = std::min(u[2], q[2]); u[3] = std::max(u[3], q[3]);
-                u[4] = std::min(u[4], q[4]); u[5] = std::max(u[5], q[5]);
-              }
-            w[v] = make_box(u, halo_lo, halo_hi, max_chunks);
-            ok = !w[v].empty && w[v].fits;
-            if (ok) wide_bytes += (int64_t)w[v].cpr * kStageChunk * w[v].rows;
-          }
-          const int64_t sq_bytes = (int64_t)ta.cpr * kStageChunk * ta.rows + (int64_t)tb.cpr * kStageChunk * tb.rows;
-          if (ok && wide_bytes * 100 <= sq_bytes * wide_pct) {
-            emit(w[0], kTileWide64, ox + 64 * h, oy, 64, 16);
-            emit(w[1], kTileWide64, ox + 64 * h, oy + 16, 64, 16);
-            half_done[h] = true;
-          }
-        }
-      }
-      for (int k = 0; k < 4; k++) {
-        if (tile[k].empty || half_done[k >> 1]) continue;
-        if (tile[k].fits) {
-          emit(tile[k], kTileStaged32, ox + 32 * k, oy, 32, 32);
-          continue;
-        }
-        for (int qd = 0; qd < 4; qd++) {
-          const Box sub = make_box(b + 6 * (8 + 4 * k + qd), halo_lo, halo_hi, max_chunks);
-          if (sub.empty) continue;
-          emit(sub, sub.fits ? kTileStaged16 : kTileDirect16, ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, 16, 16);
-        }
-      }
-    }
-  if (tiles.size() > 0x7fffffff || tlut_words > 0x7fffffff) return false;
-
-  // staged tiles first, direct tiles behind them in the same buffer
-  const size_t nstaged = tiles.size();
-  tiles.insert(tiles.end(), direct.begin(), direct.end());
-  if (!plan->tiles.reserve(tiles.size() * sizeof(TileDesc)) ||
-      !plan->tlut.reserve((size_t)(tlut_words > 0 ? tlut_words : 1) * sizeof(uint32_t)))
-    return false;
-  if (hipMemcpyAsync(plan->tiles.as<void>(), tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
-                     stream) != hipSuccess)
-    return false;
-  if (launch_tile_lut(d_lut, dw, dh, sw, plan->tiles.as<TileDesc>(), (int)nstaged, halo_lo,
-                      plan->tlut.as<uint32_t>(), stream) != hipSuccess)
-    return false;
-  if (hipStreamSynchronize(stream) != hipSuccess) return false;
-  plan->ntiles = (int)nstaged;
-  plan->n32 = n32;
-  plan->nstrip = nstrip;
-  plan->n16 = n16;
-  plan->ndirect = ndirect;
-  plan->staged_bytes = staged_bytes;
-  plan->valid = true;
-  if (getenv("T360_VERBOSE"))
-    printf("transform360: gather plan %dx%d <- %dx%d: %d staged tiles (%d strips 128x8, %d tiles 32x32, %d tiles 16x16) + "
-           "%d direct, %.2f MB staged per plane (%.2fx the source plane)\n",
-           dw, dh, sw, sh, plan->ntiles, nstrip, n32, n16, ndirect, staged_bytes / 1e6,
-           (double)staged_bytes / ((double)sw * sh));
-  if (getenv("T360_VERBOSE") && nwide) printf("transform360:   %d tiles 64x16\n", nwide);
-  if (getenv("T360_VERBOSE")) {
-    printf("transform360:   chunks per row (16 B each): ");
-    for (int c = 0; c < 64; c++)
-      if (cpr_hist[c]) printf("%d:%d ", c, cpr_hist[c]);
-    printf("\n");
+    out->ntiles = (int)out->tiles.size();
+    out->ndirect = (int)direct_.size();
+    out->tiles.insert(out->tiles.end(), direct_.begin(), direct_.end());
+    if (out->tlut.empty()) out->tlut.push_back(kWordDead);
+    if (out->chunks.empty()) out->chunks.push_back(0);
+    return out->tlut.size() < 0x7fffffffu && out->chunks.size() < 0x7fffffffu;
   }
-  return true;
+
+ private:
+  const LutEntry* lut_;
+  int dw_, dh_, sw_, sh_;
+  PlanOptions opt_;
+  int lo_, hi_, max_pos_;
+  mutable std::vector<TileDesc> direct_;
+};
+
+}  // namespace
+
+bool plan_gather(const LutEntry* lut, int dw, int dh, int sw, int sh, const PlanOptions& opt, HostGatherPlan* out) {
+  if (!(opt.ks == 1 || opt.ks == 2 || opt.ks == 4 || opt.ks == 8) || dw <= 0 || dh <= 0 || sw <= 0 || sh <= 0 ||
+      (sw % kStageChunk) != 0 || dw > 32767 || dh > 32767)
+    return false;
+  Planner p(lut, dw, dh, sw, sh, opt);
+  return p.run(out);
 }
 
 // Re-pack OpenCV's Q15 table of a ks x ks interpolation for v_dot4 (layout: t360_internal.h pack_dwords):
@@ -273,10 +418,9 @@ void pack_weights(const std::vector<int16_t>& tab, int ks, std::vector<uint32_t>
         o[r * win + q] = hi;
         o[nw + r * win + q] = lo;
       }
-    o[2 * nw] = (uint32_t)((1 << (kCoefBits - 1)) + 128 * 256 * sum_hi);
+    // pixels enter the signed part as p - 128:  SUM p*w = 256 * (SUM (p-128)*wh + 128 * SUM wh) + SUM p*wl
+    o[2 * nw] = (uint32_t)(128 * sum_hi);
   }
 }
-
-void pack_cubic_weights(const std::vector<int16_t>& tab, std::vector<uint32_t>* out) { pack_weights(tab, 4, out); }
 
 }  // namespace t360

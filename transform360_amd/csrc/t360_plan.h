@@ -1,31 +1,49 @@
-// t360_plan.h -- tile work list of the LDS-tiled gather for one map (see t360_plan.cpp).
+// t360_plan.h -- init-time planning of the LDS-tiled gather for one map (see t360_plan.cpp).
+//
+// Pure host C++ (no HIP): the planner works on a host copy of the sample LUT, so it can be unit-tested
+// and simulated on a machine without a GPU (tools/plan_sim.py).
 #pragma once
 
-#include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include <vector>
 
 #include "t360_internal.h"
-#include "t360_kernels.h"
-#include "t360_devbuf.h"
 
 namespace t360 {
 
-struct GatherPlan {
-  bool valid = false;
-  int ntiles = 0;            // staged tiles (first in `tiles`); the ndirect direct tiles follow them
-  int n32 = 0, n16 = 0, nstrip = 0, ndirect = 0;
-  int64_t staged_bytes = 0;  // sum of staged box bytes over the plane (L2 -> LDS traffic per frame)
-  DeviceBuffer tiles;        // TileDesc[ntiles]
-  DeviceBuffer tlut;         // box-relative LUT words
+struct PlanOptions {
+  int ks = 4;            // taps per axis of the interpolation: 1, 2, 4, 8
+  int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces per copy (<= kMaxPieces)
+  int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
+  int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
+  int band = 4;          // region rows walked column by column (execution order, see t360_plan.cpp)
+  int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
+  bool model_stats = false;  // fill PlanStats::lds_cycles_model (tools/plan_sim.py)
 };
 
-// d_lut: absolute LUT of the map (dw x dh entries), source plane sw x sh, ksize = taps per axis.
-// max_box_bytes: largest staged box (the DMA ring must hold two of them).
-bool build_gather_plan(const LutEntry* d_lut, int dw, int dh, int sw, int sh, int ksize, int max_box_bytes,
-                       hipStream_t stream, GatherPlan* plan);
+struct PlanStats {
+  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0;
+  int64_t fetched_bytes = 0;   // distinct source chunks fetched per frame x 16 (HBM/L2 -> LDS, one copy)
+  int64_t lds_bytes = 0;       // LDS positions per frame x 16 (incl. holes), one copy
+  int64_t direct_pixels = 0;
+  int64_t lds_cycles_model = 0;  // modelled ds_read_b64 LDS cycles (32-lane groups x stencil rows), summed over the tiles
+  int pieces_hist[33] = {0};   // staged tiles per size (1 KiB pieces per copy)
+};
 
-void pack_cubic_weights(const std::vector<int16_t>& q15_table, std::vector<uint32_t>* out);
+struct HostGatherPlan {
+  std::vector<TileDesc> tiles;    // staged tiles in execution order, then the direct tiles
+  int ntiles = 0, ndirect = 0;
+  std::vector<uint32_t> tlut;     // pixel words, lane order (tile_word())
+  std::vector<uint32_t> chunks;   // per staged tile 64 * pieces entries: chunk_entry()
+  PlanStats stats;
+};
+
+// lut: dw x dh entries (host memory); source plane sw x sh with sw % 16 == 0 (the DMA path's precondition:
+// a staged chunk never straddles the +-180 degree seam).
+bool plan_gather(const LutEntry* lut, int dw, int dh, int sw, int sh, const PlanOptions& opt, HostGatherPlan* out);
+
+// Re-pack OpenCV's Q15 table of a ks x ks interpolation for v_dot4 (layout: t360_internal.h pack_dwords)
 void pack_weights(const std::vector<int16_t>& q15_table, int ks, std::vector<uint32_t>* out);
 
 }  // namespace t360

@@ -5,6 +5,7 @@
 // per frame, per plane _transformFramePlane -> _delete.
 #include "t360_transform.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -182,26 +183,21 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
       return;
     }
   if (hipEventCreateWithFlags(&lp_fork_, hipEventDisableTiming) != hipSuccess) return;
-  if (hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&fork_event_, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&join_event_, hipEventDisableTiming) != hipSuccess) {
-    printf("transform360: could not create the auxiliary stream (%s)\n", hipGetErrorString(hipGetLastError()));
-    return;
-  }
-  if (const char* e = getenv("T360_RING_KB")) {
-    const int v = atoi(e);
-    if (v >= 8 && v <= 160) ring_bytes_ = v * 1024;
-  }
-  if (getenv("T360_NO_DMA")) use_dma_ = false;
-  if (const char* e = getenv("T360_VARIANT")) dma_variant_ = atoi(e) & 31;
-  if (const char* e = getenv("T360_LOADERS")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 4) loader_waves_ = v;
-  }
+#ifdef T360_INSTRUMENT
+  // tuning switches of the instrumented build (tools/ab.sh); the shipped library reads no environment
+  if (const char* e = getenv("T360_RING_SLOTS")) ring_slots_ = atoi(e);
+  if (const char* e = getenv("T360_MAX_PIECES")) max_pieces_ = atoi(e);
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4096) frames_per_block_ = v;
   }
+  if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
+  if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
+  if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
+  if (const char* e = getenv("T360_ROW_PAD")) plan_row_pad_ = atoi(e);
+  if (getenv("T360_NO_TILED")) use_tiled_ = false;
+  if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
+#endif
   ok_ = true;
 }
 
@@ -209,10 +205,6 @@ VideoFrameTransform::~VideoFrameTransform() {
   if (!ok_) return;
   DeviceGuard g(device_);
   (void)hipStreamSynchronize(stream_);
-  if (aux_stream_) {
-    (void)hipStreamSynchronize(aux_stream_);
-    (void)hipStreamDestroy(aux_stream_);
-  }
   for (int k = 0; k < 3; k++) {
     if (lp_streams_[k]) {
       (void)hipStreamSynchronize(lp_streams_[k]);
@@ -221,8 +213,6 @@ VideoFrameTransform::~VideoFrameTransform() {
     if (lp_join_[k]) (void)hipEventDestroy(lp_join_[k]);
   }
   if (lp_fork_) (void)hipEventDestroy(lp_fork_);
-  if (fork_event_) (void)hipEventDestroy(fork_event_);
-  if (join_event_) (void)hipEventDestroy(join_event_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -313,12 +303,17 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   }
   DeviceGuard g(device_);
   PlaneState& p = planes_[idx];
+  p.valid = false;  // a failure below must not leave the previous map half replaced
 
   MapGenParams P;
   memset(&P, 0, sizeof(P));
   P.map_w = (int)(ctx_.width_scale_factor * outputWidth + 0.5);    // :524
   P.map_h = (int)(ctx_.height_scale_factor * outputHeight + 0.5);  // :525-526
   if (P.map_w <= 0 || P.map_h <= 0) return false;
+  if (P.map_w > 32767 || P.map_h > 32767) {
+    printf("Could not generate map for plane %d. Error: output plane larger than 32767\n", idx);
+    return false;
+  }
   P.in_w = inputWidth;
   P.in_h = inputHeight;
   P.input_layout = (int)ctx_.input_layout;
@@ -449,19 +444,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     return check(hipErrorOutOfMemory, "hipMalloc(map)");
   if (!check(launch_mapgen(P, p.map.as<float2>(), p.lut.as<LutEntry>(), stream_), "mapgen launch")) return false;
   if (!ensureWeights()) return false;
-  {
-    // tile work list of the LDS-tiled gather (bicubic + BORDER_WRAP only in this round)
-    const bool barrel = olay == LAYOUT_BARREL || olay == LAYOUT_BARREL_SPLIT;
-    p.plan.valid = false;
-    const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
-    const bool tile_it = ks == 4 || (ks != 0 && !getenv("T360_TILED_CUBIC_ONLY"));
-    if (tile_it && !barrel && !getenv("T360_NO_TILED")) {
-      if (!build_gather_plan(p.lut.as<LutEntry>(), P.map_w, P.map_h, inputWidth, inputHeight, ks,
-                             ((ring_bytes_ / 2 - 64) / 1024) * 1024,  // a ring slot = whole KiB pieces + 64
-                             stream_, &p.plan))
-        return check(hipErrorUnknown, "gather plan");
-    }
-  }
+  if (!buildGatherPlan(p, P, inputWidth, inputHeight)) return false;
 
   p.in_w = inputWidth;
   p.in_h = inputHeight;
@@ -488,7 +471,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
       // register-only Q8 kernel (t360_lowpass.hip): fixed-point segment, horizontal taps that fit
       // a byte (<= 64 of them), 3/5/7 vertical taps shared by all eligible segments of the plane
       bool fast = s.fixed_point && s.kx_q8.size() <= 64 && (s.ky_q8.size() == 3 || s.ky_q8.size() == 5 || s.ky_q8.size() == 7) &&
-                  (p.fast_ky == 0 || p.fast_ky == (int)s.ky_q8.size()) && !getenv("T360_NO_FAST_LOWPASS");
+                  (p.fast_ky == 0 || p.fast_ky == (int)s.ky_q8.size()) && use_fast_lowpass_;
       for (int v : s.kx_q8) fast = fast && v >= 0 && v <= 255;
       d.kxp_off = (int)pk.size();
       d.kx_groups = 0;
@@ -895,19 +878,30 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   }
 
   // ---- stage 2: gather ----
+  // Planes with a tile plan and 16-byte friendly buffers go into fused launches of the LDS-tiled kernel
+  // (up to 4 planes each: Y, U and V of a yuv420p batch are ONE launch); everything else -- BARREL outputs
+  // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
   TiledArgs fused;
-  memset(&fused, 0, sizeof(fused));
-  fused.wtab = weights_.as<int16_t>();
-  fused.wpack = weights_pack_.as<uint32_t>();
-  fused.nframes = n_frames;
-  fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
-  fused.ring_bytes = ring_bytes_;
-  fused.loader_waves = loader_waves_;
-  fused.variant = dma_variant_;
-  fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
-  fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
+  auto reset_fused = [&]() {
+    memset(&fused, 0, sizeof(fused));
+    fused.wtab = weights_.as<int16_t>();
+    fused.wpack = weights_pack_.as<uint32_t>();
+    fused.nframes = n_frames;
+    fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
+    fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
+    fused.max_pieces = max_pieces_;
+    fused.ring_slots = ring_slots_;
+  };
+  auto flush_fused = [&]() -> bool {
+    if (fused.nplanes == 0) return true;
+    fused.direct_blocks = (fused.total_direct + 7) & ~7;
+    const bool ok = check(launch_remap_tiled(fused, stream_), "tiled remap launch");
+    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.max_pieces, fused.ring_slots);
+    reset_fused();
+    return ok;
+  };
+  reset_fused();
   const bool multi = n_frames > 1;
-  TiledArgs direct = fused;  // the pole tiles too large to stage, all planes in one small launch
   for (int k = 0; k < njobs; k++) {
     const PlaneJob& j = jobs[k];
     PlaneState& p = planes_[j.idx];
@@ -917,15 +911,14 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
                  "fill launch"))
         return false;
     }
-    // chunks go global -> LDS by DMA only from 16-byte friendly buffers; the register-staged
-    // fallback exists for bicubic only, other interpolations then use the general gather
+    // chunks go global -> LDS by DMA: 16-byte friendly source buffers only
     const bool vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
                         (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
-    if (p.plan.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && (interp == CUBIC || (vec_ok && use_dma_))) {
+    if (p.plan.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && vec_ok) {
       TiledPlane tp;
       memset(&tp, 0, sizeof(tp));
       tp.src = s.ptr;
-      tp.src_frame_bytes = (fused.debug & 64) ? 0 : s.frame_bytes;  // bit6: every frame reads frame 0 (cache-resident input)
+      tp.src_frame_bytes = s.frame_bytes;
       tp.dst = j.out;
       tp.dst_frame_bytes = j.out_frame_bytes;
       tp.sw = j.in_w;
@@ -936,23 +929,16 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       tp.dstride = j.out_stride;
       tp.tiles = p.plan.tiles.as<TileDesc>();
       tp.tlut = p.plan.tlut.as<uint32_t>();
+      tp.chunks = p.plan.chunks.as<uint32_t>();
       tp.lut = p.lut.as<LutEntry>();
       tp.ntiles = p.plan.ntiles;
+      tp.ndirect = p.plan.ndirect;
       tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
                         (!multi || (j.out_frame_bytes & 3) == 0);
-      tp.src_vec_ok = vec_ok;
-      tp.ndirect = p.plan.ndirect;
-      if (tp.ndirect > 0 && direct.nplanes < 4) direct.plane[direct.nplanes++] = tp;
-      if (tp.src_vec_ok && use_dma_ && fused.nplanes < 4) {
-        fused.plane[fused.nplanes++] = tp;
-        fused.total_tiles += tp.ntiles;
-      } else {
-        TiledArgs one = fused;
-        one.nplanes = 1;
-        one.plane[0] = tp;
-        one.total_tiles = tp.ntiles;
-        if (!check(launch_remap_tiled_cubic_regs(one, stream_), "tiled remap launch")) return false;
-      }
+      if (fused.nplanes == 4 && !flush_fused()) return false;
+      fused.plane[fused.nplanes++] = tp;
+      fused.total_tiles += tp.ntiles;
+      fused.total_direct += tp.ndirect;
       continue;
     }
     GatherArgs a;
@@ -971,52 +957,49 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     a.interp = interp;
     a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
     if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
+    last_kernel_ = "remap_gather_kernel";
   }
-  if (direct.nplanes > 0) {
-    // fork: the direct tiles write pixels no staged tile writes, so they run beside the main
-    // gather on the handle's auxiliary stream and join before the call's work is complete
-    if (!check(hipEventRecord(fork_event_, stream_), "hipEventRecord") ||
-        !check(hipStreamWaitEvent(aux_stream_, fork_event_, 0), "hipStreamWaitEvent") ||
-        !check(launch_remap_direct_cubic(direct, aux_stream_), "direct tiles launch") ||
-        !check(hipEventRecord(join_event_, aux_stream_), "hipEventRecord"))
-      return false;
-  }
-  if (fused.nplanes > 0) {
-    const char* trace_path = getenv("T360_TRACE");  // schedule debugging: dump per-workgroup timestamps
-    t360::DeviceBuffer trace;
-    size_t nwg = 0;
-    if (trace_path) {
-      const int groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
-      nwg = (size_t)fused.total_tiles * groups;
-      if (trace.reserve(nwg * 8 * sizeof(unsigned long long)) &&
-          hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
-        fused.trace = trace.as<unsigned long long>();
-    }
-    if (fused.variant & 8) {
-      if (persist_slots_ <= 0) {
-        hipDeviceProp_t prop;
-        if (!check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return false;
-        const int per_cu = getenv("T360_PERSIST_PER_CU") ? atoi(getenv("T360_PERSIST_PER_CU")) : 4;
-        persist_slots_ = prop.multiProcessorCount * (per_cu > 0 ? per_cu : 4);
-      }
-      if (!work_counters_.reserve(8 * sizeof(int))) return check(hipErrorOutOfMemory, "hipMalloc(counters)");
-      if (!check(hipMemsetAsync(work_counters_.as<void>(), 0, 8 * sizeof(int), stream_), "hipMemsetAsync")) return false;
-      fused.work_counters = work_counters_.as<int>();
-      fused.persist_slots = persist_slots_;
-    }
-    if (!check(launch_remap_tiled_cubic_dma(fused, stream_), "tiled remap launch")) return false;
-    if (fused.trace) {
-      std::vector<unsigned long long> host(nwg * 8);
-      if (hipStreamSynchronize(stream_) == hipSuccess &&
-          hipMemcpy(host.data(), trace.as<void>(), nwg * 64, hipMemcpyDeviceToHost) == hipSuccess) {
-        if (FILE* f = fopen(trace_path, "wb")) {
-          fwrite(host.data(), 8, host.size(), f);
-          fclose(f);
-        }
-      }
-    }
-  }
-  if (direct.nplanes > 0 && !check(hipStreamWaitEvent(stream_, join_event_, 0), "hipStreamWaitEvent")) return false;
+  return flush_fused();
+}
+
+// Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host once and planned
+// there (t360_plan.cpp).  Planes the tiled kernel cannot take (BARREL outputs, widths that are not multiples
+// of 16) simply have no plan and use the general gather.
+bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, int in_w, int in_h) {
+  p.plan.valid = false;
+  const bool barrel = P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT;
+  const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
+  if (ks == 0 || barrel || !use_tiled_ || (in_w & 15) != 0) return true;
+  const size_t n = (size_t)P.map_w * (size_t)P.map_h;
+  std::vector<LutEntry> lut(n);
+  if (!check(hipMemcpyAsync(lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
+      !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+    return false;
+  PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces_;
+  o.wide_pct = plan_wide_pct_;
+  o.strip_pct = plan_strip_pct_;
+  o.band = plan_band_;
+  o.row_pad = plan_row_pad_;
+  HostGatherPlan hp;
+  if (!plan_gather(lut.data(), P.map_w, P.map_h, in_w, in_h, o, &hp)) return true;  // not plannable: general gather
+  if (!p.plan.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
+      !p.plan.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !p.plan.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
+    return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
+  if ((!hp.tiles.empty() &&
+       !check(hipMemcpyAsync(p.plan.tiles.as<void>(), hp.tiles.data(), hp.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
+                             stream_), "hipMemcpy(tiles)")) ||
+      !check(hipMemcpyAsync(p.plan.tlut.as<void>(), hp.tlut.data(), hp.tlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                            stream_), "hipMemcpy(tlut)") ||
+      !check(hipMemcpyAsync(p.plan.chunks.as<void>(), hp.chunks.data(), hp.chunks.size() * sizeof(uint32_t),
+                            hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
+      !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+    return false;
+  p.plan.ntiles = hp.ntiles;
+  p.plan.ndirect = hp.ndirect;
+  p.plan.stats = hp.stats;
+  p.plan.valid = true;
   return true;
 }
 
@@ -1126,6 +1109,19 @@ bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int w
   }
   DeviceGuard g(device_);
   return runLowpass(planes_[idx], d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx, stream_);
+}
+
+bool VideoFrameTransform::planStats(int idx, int64_t* st) const {
+  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid || !planes_[idx].plan.valid) return false;
+  const PlaneState::GatherPlan& g = planes_[idx].plan;
+  st[0] = g.ntiles;
+  st[1] = g.ndirect;
+  st[2] = g.stats.fetched_bytes;
+  st[3] = g.stats.lds_bytes;
+  st[4] = g.stats.direct_pixels;
+  st[5] = (int64_t)(g.tiles.size() + g.tlut.size() + g.chunks.size());
+  st[6] = st[7] = 0;
+  return true;
 }
 
 bool VideoFrameTransform::getMapSize(int idx, int* w, int* h) const {

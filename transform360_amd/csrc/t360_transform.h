@@ -59,6 +59,8 @@ class VideoFrameTransform {
   int segmentCount(int idx) const;
   bool getSegment(int idx, int i, int* rect4, int* lens2, int* fixed_point) const;
   bool copySegmentKernels(int idx, int i, float* kx, float* ky) const;
+  const char* lastKernel() const { return last_kernel_.c_str(); }
+  bool planStats(int idx, int64_t* stats8) const;
 
  private:
   struct PlaneState {
@@ -85,13 +87,19 @@ class VideoFrameTransform {
     t360::DeviceBuffer tiles_fast, tiles_rest;
     int nfast = 0, nrest = 0, max_rows_rest = 0, fast_lds_bytes = 0;
     bool full_cover = false;
-    // LDS-tiled gather
-    t360::GatherPlan plan;
+    // LDS-tiled gather: work list planned on the host at init (t360_plan.cpp)
+    struct GatherPlan {
+      bool valid = false;
+      int ntiles = 0, ndirect = 0;          // staged tiles first in `tiles`, the direct tiles behind them
+      t360::DeviceBuffer tiles, tlut, chunks;
+      t360::PlanStats stats;
+    } plan;
   };
 
   bool check(hipError_t e, const char* what) const;
   bool ensureWeights();
   bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
+  bool buildGatherPlan(PlaneState& p, const t360::MapGenParams& P, int in_w, int in_h);
   // all-device core: a set of planes of n frames
   struct PlaneJob {
     const uint8_t* in;
@@ -115,8 +123,6 @@ class VideoFrameTransform {
   int device_ = 0;
   hipStream_t own_stream_ = nullptr;
   hipStream_t stream_ = nullptr;
-  hipStream_t aux_stream_ = nullptr;  // direct (unstaged) pole tiles run here beside the main gather
-  hipEvent_t fork_event_ = nullptr, join_event_ = nullptr;
   // the low-pass launches of planes 1.. of a batch run beside plane 0's (independent planes, small grids)
   hipStream_t lp_streams_[3] = {nullptr, nullptr, nullptr};
   hipEvent_t lp_fork_ = nullptr, lp_join_[3] = {nullptr, nullptr, nullptr};
@@ -124,15 +130,16 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  int ring_bytes_ = 36 * 1024;  // LDS ring of the DMA-staged gather: 4 workgroups (78 VGPRs, 5 waves each) per CU
-                                // (VGPR-limited, measured), 3 x 48 KiB fits the 160 KiB LDS
-  bool use_dma_ = true;
-  int loader_waves_ = 1;
-  int dma_variant_ = 1;  // T360_VARIANT: bit0 LDS reads in groups of 2 px (78 VGPRs), bit2 no loader wave, bit3 persistent, bit4 flags
+  // LDS-tiled gather: staging budget per tile and copy (1 KiB pieces) and frames in flight per workgroup; the
+  // pair selects the kernel instantiation (8, 2: two 16 KiB slots = 32.9 KiB of LDS, 4 workgroups per CU)
+  int max_pieces_ = 8;
+  int ring_slots_ = 2;
   int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
+  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 4, plan_row_pad_ = 0;  // PlanOptions
+  bool use_tiled_ = true;
+  std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
+  bool use_fast_lowpass_ = true;
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
-  t360::DeviceBuffer work_counters_;  // item queues of the persistent gather kernel (8 ints)
-  int persist_slots_ = 0;             // resident workgroup slots of the device for that kernel
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
 };

@@ -133,6 +133,18 @@ class VideoFrameTransform:
         op, _, _, ostride = _plane_ptr(d_out)
         return bool(self._l.T360_filterPlane(self._h, ip, op, iw, ih, istride, ostride, map_index))
 
+    def lastKernel(self):
+        """Name of the gather kernel the most recent transform call launched."""
+        return (self._l.T360_lastKernel(self._h) or b"").decode()
+
+    def planStats(self, map_index):
+        """dict of the gather plan of `map_index`, or None when the plane uses the general gather."""
+        st = (C.c_int64 * 8)()
+        if not self._l.T360_getPlanStats(self._h, map_index, st):
+            return None
+        return dict(staged_tiles=st[0], direct_tiles=st[1], fetched_bytes=st[2], lds_bytes=st[3],
+                    direct_pixels=st[4], table_bytes=st[5])
+
     def map(self, map_index):
         """The float warp map of `map_index` as an [h, w, 2] float32 array (warpMats_[idx])."""
         w, h = C.c_int(), C.c_int()
