@@ -241,10 +241,10 @@ def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
 # runs of ring geometries and plan options; every one of those switches must leave the pixels alone.  It is a second
 # library, so it runs in a child process (tests/run_variants.py) with T360_LIB pointing at it.
 VARIANTS = [
-    {"T360_RING_SLOTS": "3"}, {"T360_MAX_PIECES": "6", "T360_RING_SLOTS": "3"}, {"T360_MAX_PIECES": "12"},
-    {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"}, {"T360_WIDE64": "1000"}, {"T360_BAND": "1"},
-    {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"}, {"T360_FRAMES_PER_BLOCK": "3", "T360_RING_SLOTS": "3"},
-    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+    {"T360_RING_KB": "31", "T360_MAX_PIECES": "12"}, {"T360_RING_KB": "26", "T360_MAX_PIECES": "12"}, {"T360_MAX_PIECES": "8"}, {"T360_MAX_PIECES": "4"},
+    {"T360_ROW_ALIGN": "1"}, {"T360_ROW_ALIGN": "4"}, {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"},
+    {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
+    {"T360_FRAMES_PER_BLOCK": "3", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
 ]
 
 
@@ -267,7 +267,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
     from transform360_amd import _lib
     assert _lib.load().T360_buildFlags() == 0
     # a switch of the instrumented build must be inert here: same kernel instantiation as without it
-    monkeypatch.setenv("T360_RING_SLOTS", "3")
+    monkeypatch.setenv("T360_RING_KB", "26")
     monkeypatch.setenv("T360_NO_TILED", "1")
     import torch
     with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
@@ -276,7 +276,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
         dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
         _ready()
         assert t.transformFramePlane(src, dst, 0)
-        assert t.lastKernel() == "remap_tiled_kernel<4, 8, 2>"
+        assert t.lastKernel() == "remap_tiled_kernel<4, 38>"
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)

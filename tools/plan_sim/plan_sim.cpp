@@ -13,8 +13,10 @@ extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, 
   o.max_pieces = max_pieces;
   o.wide_pct = wide_pct;
   o.strip_pct = strip_pct;
-  o.row_pad = row_pad;
-  (void)unused;
+  o.row_pad = row_pad & 255;
+  o.row_align = ((row_pad >> 8) & 255) ? ((row_pad >> 8) & 255) : 1;
+  o.row_search = (row_pad >> 16) != 0;
+  o.model_b_shift = unused;
   o.model_stats = true;
   t360::HostGatherPlan plan;
   if (!t360::plan_gather(lut, dw, dh, sw, sh, o, &plan)) return 0;

@@ -67,8 +67,8 @@ def main():
     ap.add_argument("--pieces", type=str, default="12")
     ap.add_argument("--wide", type=str, default="200")
     ap.add_argument("--strip", type=str, default="0")
-    ap.add_argument("--row-pad", type=str, default="0")
-    ap.add_argument("--slack", type=int, default=3)
+    ap.add_argument("--row-pad", type=str, default="0", help="pad + 256 * row_align, e.g. 2048 = align 8")
+    ap.add_argument("--bshift", type=str, default="0")
     a = ap.parse_args()
     L = build()
     lut, (sw, sh), (dw, dh), ks = lut_for(a.config, a.plane)
@@ -77,18 +77,19 @@ def main():
         for wide in [int(v) for v in a.wide.split(",")]:
             for strip in [int(v) for v in a.strip.split(",")]:
                 for pm in [int(v) for v in a.row_pad.split(",")]:
+                  for bs in [int(v) for v in a.bshift.split(",")]:
                     st = (C.c_longlong * 80)()
-                    ok = L.t360_plan_sim(lut.ctypes.data, dw, dh, sw, sh, ks, pieces, wide, strip, pm, a.slack, st)
+                    ok = L.t360_plan_sim(lut.ctypes.data, dw, dh, sw, sh, ks, pieces, wide, strip, pm, bs, st)
                     assert ok
                     src = sw * sh
                     ntile = st[0] + st[1] + st[2] + st[3]
                     hist = {i: st[12 + i] for i in range(33) if st[12 + i]}
-                    print("pieces %2d wide %3d strip %3d pad %d: strips %d wide %d sq %d s16 %d direct %d (%d px) | fetched %.2f MB = %.3fx "
+                    print("bshift %d pieces %2d wide %3d strip %3d pad %d: strips %d wide %d sq %d s16 %d direct %d (%d px) | fetched %.2f MB = %.3fx "
                           "src | LDS %.2f MB (%.3fx fetched) | max pieces %d | model %.2f LDS cycles per 32-lane read "
                           "| tables %.1f+%.1f MB" % (
-                              pieces, wide, strip, pm, st[0], st[1], st[2], st[3], st[4], st[7], st[5] / 1e6, st[5] / src,
+                              bs, pieces, wide, strip, pm, st[0], st[1], st[2], st[3], st[4], st[7], st[5] / 1e6, st[5] / src,
                               st[6] / 1e6, st[6] / max(st[5], 1), st[11],
-                              st[8] / max(1, ((st[0] + st[1] + st[2]) * 32 + st[3] * 8) * ks), st[9] / 1e6, st[10] / 1e6))
+                              st[8] / max(1, ((st[0] + st[1] + st[2]) * 32 + st[3] * 8) * ks * 2), st[9] / 1e6, st[10] / 1e6))
                     print("   tile sizes (pieces: tiles):", hist)
 
 

@@ -58,5 +58,8 @@ int main() {
   run<8>(320, 1024, B, 50); run<48>(320, 1024, B, 50); run<64>(320, 1024, B, 50);
   run<48>(320, 26 * 1024, B, 50); run<48>(256, 26 * 1024, B, 50); run<48>(256, 20 * 1024, B, 50); run<48>(256, 40 * 1024, B, 50);
   run<48>(64, 1024, B, 50); run<48>(128, 1024, B, 50);
+  // round 2: the tiled gather's shape (5 waves, ~88 VGPRs) against LDS per workgroup
+  for (int kb : {32, 36, 38, 39, 40, 48, 50, 52}) run<76>(320, kb * 1024, B, 50);
+  for (int kb : {32, 38, 40}) run<64>(320, kb * 1024, B, 50);
   return 0;
 }

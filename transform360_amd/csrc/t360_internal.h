@@ -94,7 +94,7 @@ enum : int {
 
 constexpr int kStageChunk = 16;   // bytes per staged chunk (one dwordx4 per DMA lane)
 constexpr int kPieceChunks = 64;  // chunks per DMA instruction (one per lane): a 1 KiB "piece"
-constexpr int kMaxPieces = 16;    // pieces per copy of a tile's staged region (the loader keeps 16 offsets per lane)
+constexpr int kMaxPieces = 16;    // pieces of a tile's staged region (each of the 4 waves moves up to 4)
 
 // One unit of gather work.  The staged region of a tile is NOT a bounding box: the planner lists exactly the
 // 16-byte source chunks the tile's stencils touch (the footprint of an output tile in the equirect source is a
@@ -105,13 +105,10 @@ struct __attribute__((aligned(16))) TileDesc {
   int16_t ox, oy;     // output origin
   int16_t kind;       // kTile*
   int16_t flags;      // kTilePartial | kTileSeamShift
-  int32_t tlut;       // first pixel word of this tile (lane order)
-  int32_t chunks;     // first entry of the tile's chunk table: 64 * pieces entries (chunk_entry()), followed by
-                      // the row table (2 int16 per dword)
   int16_t pieces;     // 1 KiB DMA pieces per copy of the staged region
   int16_t rows;       // box rows (entries of the row table)
   int32_t fetched;    // distinct source chunks among the positions (statistics)
-  int32_t pad[2];
+  int32_t pad[4];
 };
 static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 
@@ -121,12 +118,19 @@ static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 //   bits 19..28  sub-pixel phase
 //   bit 31       pixel outside the plane (partial tile)
 // LDS byte offset of the tap at stencil row k = row_base[row + k] * 16 + x, with the tile's row table
-// (int16 per box row, in 16-byte chunks: LDS position of the row minus its first staged column) stored behind
-// the tile's chunk table.
+// (int16 per box row, in 16-byte chunks: LDS position of the row minus its first staged column).
+//
+// Per-tile tables live at FIXED strides, so a workgroup can fetch them from its tile index alone, in parallel with
+// the descriptor (one memory round trip less in every workgroup's prologue):
+//   pixel words   tlut   + tile * tile_words(ks)           (a uint4 per lane; 16x16 tiles use its first word)
+//   chunk table   chunks + tile * tile_chunk_dwords(max_pieces):  64 * max_pieces chunk entries (the first
+//                 64 * pieces are meaningful), then the row table: 64 dwords = 128 int16
+constexpr int tile_words(int ks) { return ks == 8 ? 256 : 1024; }  // Lanczos4 plans hold 16x16 tiles only
+constexpr int tile_chunk_dwords(int max_pieces) { return max_pieces * 64 + 64; }
 constexpr uint32_t kWordDead = 0x80000000u;
 constexpr int kWordRowShift = 11, kWordFracShift = 19;
 constexpr int kBoxMaxCols = 2048 / 16;  // chunk columns of a box
-constexpr int kBoxMaxRows = 256;
+constexpr int kBoxMaxRows = 128;        // rows of a box: the row table is 64 dwords, one per lane of a wave
 // Chunk table entry: source row (already wrapped) and 16-byte column (already wrapped) of one LDS position.
 inline uint32_t chunk_entry(uint32_t sy, uint32_t cx) { return (sy << 12) | cx; }
 

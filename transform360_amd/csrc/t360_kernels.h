@@ -55,16 +55,22 @@ struct TiledArgs {
   int nplanes;
   int total_tiles;          // staged tiles of all planes
   int total_direct;         // direct tiles of all planes
-  int direct_blocks;        // total_direct rounded up to a multiple of 8 (keeps blockIdx.x % 8 = XCD for the rest)
-  int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces): selects the ring geometry
-  int ring_slots;           // frames in flight per workgroup (2 or 3)
+  int groups;               // frame groups = ceil(nframes / frames_per_block): work items per tile
+  int direct_blocks;        // total_direct * groups rounded up to a multiple of 8 (keeps blockIdx.x % 8 = XCD for the rest)
+  int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
+  int ring_kb;              // LDS per workgroup in KiB: selects the kernel instantiation (38 or 50)
+#ifdef T360_INSTRUMENT
+  int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
+                            // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B
+  unsigned long long* trace;  // instrumented build only: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
+#endif
   TiledPlane plane[4];
 };
 // One launch for all planes of a batch (<= 4): staged tiles by LDS-DMA, pole tiles gathered directly.
 // Every plane's source must be 16-byte friendly (base, stride, frame distance, width).
 hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream);
 // the instantiation launch_remap_tiled() picks for these parameters (reporting)
-const char* remap_tiled_kernel_name(int ks, int max_pieces, int ring_slots);
+const char* remap_tiled_kernel_name(int ks, int ring_kb);
 
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {

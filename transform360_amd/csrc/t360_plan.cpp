@@ -51,6 +51,7 @@ struct Foot {
   std::vector<uint8_t> mask;  // rows x ncols: chunk is part of the footprint
   std::vector<int> first, last, pos;  // per box row: marked chunk columns first..last (-1: none), LDS chunk position
   int npos = 0;           // LDS chunk positions
+  int skew = 0;           // LDS bank skew per box row, in chunks (see place())
   int pieces = 0;
   int fetched = 0;        // marked chunks
 };
@@ -112,15 +113,37 @@ class Planner {
     }
     f->fetched = fetched;
     if (fetched > max_pos_) return;
+    f->skew = 0;
     place(f);
+    if (opt_.row_search && opt_.row_align > 1 && f->feasible && opt_.ks != 1) {
+      // the skew whose modelled bank conflicts are fewest (the staircase of source rows under a row of output pixels
+      // climbs or descends depending on where the tile sits on its cube face)
+      int best = lds_cycles(*f), best_skew = 0;
+      for (int sk = 1; sk < opt_.row_align; sk++) {
+        f->skew = sk;
+        place(f);
+        if (!f->feasible) continue;
+        const int c = lds_cycles(*f);
+        if (c < best) best = c, best_skew = sk;
+      }
+      f->skew = best_skew;
+      place(f);
+    }
   }
 
-  // rows back to back
+  // LDS placement of the box rows.  Every pixel looks its stencil rows up in the row table, so rows may sit anywhere
+  // and in any order.  row_align > 1: the LDS chunk position of a row is congruent to its source chunk column
+  // (+ skew * row) modulo row_align.  With 8 (128 bytes = one sweep of the 32 banks a ds_read_b32 sees) and skew 0
+  // the bank of a staged byte depends on its source x only; the lanes of a read are neighbouring output columns
+  // whose taps span < 128 source bytes but drift over ~10 source rows, and the skew (chosen per tile by the bank
+  // model, footprint()) keeps the staircase's steps off each other's banks.  Rows are then chained greedily so that
+  // each starts where the previous one ends or a few chunks later: the padding is LDS and DMA lanes, never HBM traffic.
   void place(Foot* f) const {
     f->first.assign((size_t)f->rows, -1);
     f->last.assign((size_t)f->rows, -1);
     f->pos.assign((size_t)f->rows, 0);
-    int at = 0;
+    f->feasible = false;
+    std::vector<int> todo;
     for (int r = 0; r < f->rows; r++) {
       const uint8_t* m = &f->mask[(size_t)r * f->ncols];
       for (int c = 0; c < f->ncols; c++)
@@ -128,8 +151,27 @@ class Planner {
           if (f->first[(size_t)r] < 0) f->first[(size_t)r] = c;
           f->last[(size_t)r] = c;
         }
+      if (f->first[(size_t)r] >= 0) todo.push_back(r);
+    }
+    const int A = std::max(1, opt_.row_align);
+    int at = 0;
+    while (!todo.empty()) {
+      size_t pick = 0;
+      int gap = 0;
+      if (A > 1) {
+        int best = A;
+        for (size_t i = 0; i < todo.size() && best > 0; i++) {
+          const int r = todo[i];
+          const int g = wrap(f->c0 + f->first[(size_t)r] + f->skew * r - at, A);
+          if (g < best) best = g, pick = i;
+        }
+        gap = best;
+      }
+      const int r = todo[pick];
+      todo.erase(todo.begin() + (long)pick);
+      at += gap;
       f->pos[(size_t)r] = at;
-      if (f->first[(size_t)r] >= 0) at += f->last[(size_t)r] - f->first[(size_t)r] + 1 + row_pad(*f, r);
+      at += f->last[(size_t)r] - f->first[(size_t)r] + 1 + row_pad(*f, r);
     }
     f->npos = at;
     f->pieces = (at + kPieceChunks - 1) / kPieceChunks;
@@ -159,47 +201,51 @@ class Planner {
     return row_base(f, r) * kStageChunk + (sx - lo_ - f.c0 * kStageChunk);
   }
 
-  // Modelled LDS cycles of the tile's ds_read_b64 reads (MI355X_MICROARCH.md "LDS": two 32-lane groups per
-  // instruction, bank = dword address % 64, cycles of a group = most distinct addresses on one bank; checked on
-  // these patterns by tools/ubench/lds_patterns.hip).  Summed over the stencil rows.
+  // Modelled LDS cycles of the tile's stencil-row reads (MI355X_MICROARCH.md "LDS": a wave64 access is served in two
+  // 32-lane groups; cycles of a group = most distinct dword addresses on one bank; checked on these patterns by
+  // tools/ubench/lds_patterns.hip).  model_dual = false: two ds_read_b32 per window (dwords k and k+1 separately,
+  // bank = dword % 32); true: one ds_read_b64 on the A or B copy (bank = dword % 64).  Summed over the stencil rows.
   int lds_cycles(const Foot& f) const {
-    const int bbase = (1 << 20) + 4;  // copy B starts at a multiple of 1 KiB plus 4: only (address % 256) matters here
+    const bool dual = opt_.model_dual;
+    const int nbanks = dual ? 64 : 32;
+    const int bbase = (1 << 20) + 4 + opt_.model_b_shift;  // copy B: a multiple of 1 KiB plus 4 (+ bank stagger)
     const TileShape& s = f.shape;
     int total = 0;
     const int npx = s.npx;
     for (int g = 0; g < 8; g++) {  // 8 groups of 32 lanes
       for (int p = 0; p < npx; p++)
-        for (int k = 0; k < opt_.ks; k++) {
-          int cnt[64];
-          int addr_of[64][4];
-          memset(cnt, 0, sizeof(cnt));
-          int worst = 1;
-          for (int l = 0; l < 32; l++) {
-            const int tid = g * 32 + l;
-            int px, py;
-            if (npx == 4) {
-              px = f.ox + tid % s.w;
-              py = f.oy + (tid / s.w) * 4 + p;
-            } else {
-              px = f.ox + (tid & 15);
-              py = f.oy + (tid >> 4);
-            }
-            if (px >= dw_ || py >= dh_) continue;
-            const int off = tap_offset(f, lut_[(size_t)py * dw_ + px], k);
-            const int a = (off & ~3) + ((off & 4) ? bbase : 0);
-            for (int j = 0; j < 2; j++) {
-              const int d = (a >> 2) + j, b = d & 63;
-              bool seen = false;
-              for (int i = 0; i < cnt[b] && i < 4; i++) seen = seen || addr_of[b][i] == d;
-              if (!seen) {
-                if (cnt[b] < 4) addr_of[b][cnt[b]] = d;
-                cnt[b]++;
-                worst = std::max(worst, cnt[b]);
+        for (int k = 0; k < opt_.ks; k++)
+          for (int acc = 0; acc < (dual ? 1 : 2); acc++) {
+            int cnt[64];
+            int addr_of[64][4];
+            memset(cnt, 0, sizeof(cnt));
+            int worst = 1;
+            for (int l = 0; l < 32; l++) {
+              const int tid = g * 32 + l;
+              int px, py;
+              if (npx == 4) {
+                px = f.ox + tid % s.w;
+                py = f.oy + (tid / s.w) * 4 + p;
+              } else {
+                px = f.ox + (tid & 15);
+                py = f.oy + (tid >> 4);
+              }
+              if (px >= dw_ || py >= dh_) continue;
+              const int off = tap_offset(f, lut_[(size_t)py * dw_ + px], k);
+              const int a = dual ? (off & ~3) + ((off & 4) ? bbase : 0) : (off & ~3) + 4 * acc;
+              for (int j = 0; j < (dual ? 2 : 1); j++) {
+                const int d = (a >> 2) + j, b = d & (nbanks - 1);
+                bool seen = false;
+                for (int i = 0; i < cnt[b] && i < 4; i++) seen = seen || addr_of[b][i] == d;
+                if (!seen) {
+                  if (cnt[b] < 4) addr_of[b][cnt[b]] = d;
+                  cnt[b]++;
+                  worst = std::max(worst, cnt[b]);
+                }
               }
             }
+            total += worst;
           }
-          total += worst;
-        }
     }
     return total;
   }
@@ -220,13 +266,15 @@ class Planner {
       return;
     }
     t.kind = (int16_t)s.kind;
-    t.tlut = (int32_t)out->tlut.size();
-    t.chunks = (int32_t)out->chunks.size();
     t.pieces = (int16_t)f.pieces;
+    t.rows = (int16_t)f.rows;
     t.fetched = f.fetched;
-    // chunk table: position -> source chunk; holes repeat the previous valid entry
+    // chunk table at a fixed stride: position -> source chunk; holes repeat the previous valid entry
+    const int cstride = tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
     const size_t base = out->chunks.size();
-    out->chunks.resize(base + (size_t)f.pieces * kPieceChunks, 0xffffffffu);
+    out->chunks.resize(base + (size_t)cstride, 0);
+    const size_t used = (size_t)f.pieces * kPieceChunks;
+    std::fill(out->chunks.begin() + (long)base, out->chunks.begin() + (long)(base + used), 0xffffffffu);
     for (int r = 0; r < f.rows; r++) {
       if (f.first[(size_t)r] < 0) continue;
       const uint8_t* m = &f.mask[(size_t)r * f.ncols];
@@ -238,27 +286,28 @@ class Planner {
         }
     }
     uint32_t prev = 0xffffffffu;
-    for (size_t i = base; i < out->chunks.size() && prev == 0xffffffffu; i++) prev = out->chunks[i];
-    for (size_t i = base; i < out->chunks.size(); i++) {
+    for (size_t i = base; i < base + used && prev == 0xffffffffu; i++) prev = out->chunks[i];
+    for (size_t i = base; i < base + used; i++) {
       if (out->chunks[i] == 0xffffffffu)
         out->chunks[i] = prev;
       else
         prev = out->chunks[i];
     }
-    // row table behind the chunk table
-    t.rows = (int16_t)f.rows;
+    for (size_t i = base + used; i < base + (size_t)cstride - 64; i++) out->chunks[i] = prev;  // never staged, but in bounds
+    // row table: the last 64 dwords
     {
-      const size_t rb = out->chunks.size();
-      out->chunks.resize(rb + (size_t)(f.rows + 1) / 2, 0);
+      const size_t rb = base + (size_t)cstride - 64;
       for (int r = 0; r < f.rows; r++) {
         const uint32_t v = (uint32_t)(uint16_t)(int16_t)(f.first[(size_t)r] < 0 ? 0 : row_base(f, r));
         out->chunks[rb + (size_t)r / 2] |= v << (16 * (r & 1));
       }
     }
-    // pixel words, lane order of the gather
-    const int words = s.npx * 256;
-    out->tlut.resize(out->tlut.size() + (size_t)words, kWordDead);
-    uint32_t* w = &out->tlut[(size_t)t.tlut];
+    // pixel words at a fixed stride, lane order of the gather; 16x16 tiles of a mixed plan use the first word of a uint4
+    const int wstride = tile_words(opt_.ks);
+    const int per_lane = wstride / 256;
+    const size_t wb = out->tlut.size();
+    out->tlut.resize(wb + (size_t)wstride, kWordDead);
+    uint32_t* w = &out->tlut[wb];
     for (int tid = 0; tid < 256; tid++)
       for (int p = 0; p < s.npx; p++) {
         int px, py;
@@ -275,7 +324,7 @@ class Planner {
         if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
         const uint32_t xrel = (uint32_t)(sx - lo_ - f.c0 * kStageChunk);
         const uint32_t r0 = (uint32_t)(e.iy - lo_ - f.y0);
-        w[tid * s.npx + p] = xrel | (r0 << kWordRowShift) | ((uint32_t)e.frac << kWordFracShift);
+        w[tid * per_lane + p] = xrel | (r0 << kWordRowShift) | ((uint32_t)e.frac << kWordFracShift);
       }
     out->tiles.push_back(t);
     st.fetched_bytes += (int64_t)f.fetched * kStageChunk;
@@ -283,6 +332,32 @@ class Planner {
     st.pieces_hist[f.pieces < 32 ? f.pieces : 32]++;
     if (opt_.model_stats && opt_.ks != 1) st.lds_cycles_model += lds_cycles(f);
     (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq : st.n_16)++;
+  }
+
+  // Execution order = raster order of the tiles (row by row, left to right): horizontally adjacent tiles -- whose
+  // footprints end inside the same 128-byte lines of the source rows -- start back to back on the same XCD and
+  // walk the frames in step, so the shared lines come from HBM once and from that XCD's L2 the second time.
+  void raster_order(HostGatherPlan* out) const {
+    const size_t n = out->tiles.size();
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+      const TileDesc& x = out->tiles[a];
+      const TileDesc& y = out->tiles[b];
+      return x.oy != y.oy ? x.oy < y.oy : x.ox < y.ox;
+    });
+    const size_t ws = (size_t)tile_words(opt_.ks), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+    std::vector<TileDesc> tiles(n);
+    std::vector<uint32_t> tlut(out->tlut.size()), chunks(out->chunks.size());
+    for (size_t i = 0; i < n; i++) {
+      tiles[i] = out->tiles[idx[i]];
+      std::copy(out->tlut.begin() + (long)(idx[i] * ws), out->tlut.begin() + (long)((idx[i] + 1) * ws), tlut.begin() + (long)(i * ws));
+      std::copy(out->chunks.begin() + (long)(idx[i] * cs), out->chunks.begin() + (long)((idx[i] + 1) * cs),
+                chunks.begin() + (long)(i * cs));
+    }
+    out->tiles.swap(tiles);
+    out->tlut.swap(tlut);
+    out->chunks.swap(chunks);
   }
 
   bool run(HostGatherPlan* out) const {
@@ -365,6 +440,7 @@ class Planner {
             }
           }
         }
+    if (opt_.raster) raster_order(out);
     out->ntiles = (int)out->tiles.size();
     out->ndirect = (int)direct_.size();
     out->tiles.insert(out->tiles.end(), direct_.begin(), direct_.end());

@@ -17,8 +17,14 @@ struct PlanOptions {
   int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces per copy (<= kMaxPieces)
   int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
   int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
-  int band = 4;          // region rows walked column by column (execution order, see t360_plan.cpp)
+  int band = 4;          // raster = false: region rows walked column by column (execution order, see t360_plan.cpp)
+  bool raster = true;    // execution order = raster order of the tiles
   int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
+  int row_align = 8;     // LDS chunk position of a staged row == its source chunk column + skew * row, modulo this
+                         // (1: rows packed back to back)
+  bool row_search = true;  // per tile, the skew with the fewest modelled bank conflicts
+  bool model_dual = false;   // bank model of ds_read_b64 on two copies instead of two ds_read_b32 on one
+  int model_b_shift = 0;     // extra byte offset of copy B in the bank model (tools/plan_sim.py)
   bool model_stats = false;  // fill PlanStats::lds_cycles_model (tools/plan_sim.py)
 };
 

@@ -4,7 +4,7 @@
 // SURVEY.md Appendix A.3/A.4); written around the bicubic 4x4 stencil and instantiated for nearest,
 // bilinear and Lanczos4 as well.  Organised for MI355X:
 //
-//   * one workgroup (4 consumer waves + 1 loader wave) owns one OUTPUT tile (64x16, 32x32 or 128x8 px with
+//   * one workgroup (4 waves) owns one OUTPUT tile (64x16, 32x32 or 128x8 px with
 //     4 px per lane, lane = column; 16x16 px with 1 px per lane near the poles; the plan's choice,
 //     t360_plan.cpp) and walks `frames_per_block` frames of the batch with it.  Everything that depends only
 //     on geometry -- the LDS address of each stencil row of each pixel, the 16 Q15 weights per pixel, the
@@ -20,8 +20,9 @@
 //     ONE 8-byte aligned qword of copy A (o % 8 < 4) or copy B (o % 8 >= 4) and is fetched with ds_read_b64,
 //     which costs half the LDS cycles of the two aligned dwords (ds_read2_b32) a single copy needs
 //     (MI355X_MICROARCH.md "LDS"; tools/ubench/lds_patterns.hip).  The second write is an L1 hit.
-//   * the ring slots have a compile-time size and the frame loop is unrolled over them, so the slot base is
-//     an immediate of the ds_read: no per-frame address arithmetic at all.
+//   * ring slots come in a few compile-time sizes (the tile picks the smallest that holds it) and the frame loop
+//     is unrolled over the slots, so the slot base is an immediate of the ds_read: no per-frame address
+//     arithmetic at all, and small tiles keep more frames in flight than large ones.
 //   * the 4x4 stencil of one output pixel costs 4 ds_read_b64 + 4 v_alignbit and 8 v_dot4: weights are split
 //     into a signed high byte and an unsigned low byte (w = 256*wh + wl) and pixels enter the high part as
 //     p-128,   SUM p*w = 256 * (SUM (p-128)*wh + 128 * SUM wh) + SUM p*wl,
@@ -40,16 +41,37 @@ namespace t360 {
 
 namespace {
 
-constexpr int kLoaderWave = 4;
 
 // ---- ring geometry (compile time) -------------------------------------------------------------
-// PMAX = largest staged region of a tile in 1 KiB pieces (the plan's max_pieces); DUAL = two copies.
-template <int PMAX, bool DUAL>
-struct Ring {
-  static constexpr int kCopy = PMAX * 1024;
-  static constexpr int kCopyB = kCopy + 4;  // copy B: the same bytes, 4 further (8-byte aligned odd dwords)
-  static constexpr int kSlot = (DUAL ? 2 * kCopy : kCopy) + 64;
+// A workgroup owns RINGKB KiB of LDS.  A tile of p pieces (1 KiB of staged source each) uses the smallest slot
+// class P >= p; its ring then holds K = min(4, ring / slot) frames.  Slot sizes are compile-time constants so
+// that the slot base is an immediate of the consumer's ds_read (the frame loop is unrolled over the K slots):
+// most tiles stage 4-8 KiB and keep 4 frames in the ring, the few large ones near the poles 2-3.
+constexpr int kMaxSlots = 4;
+// T360_DUAL: 1 = every chunk is staged twice (copy B four bytes further) so that each stencil-row window is ONE aligned
+// ds_read_b64; 0 = one copy, two aligned ds_read_b32 per window: twice the LDS read cycles, but half the LDS per frame in
+// flight.  The gather is bound by bytes in flight (HBM latency x bandwidth), not by LDS cycles: 0 measured faster.
+#ifndef T360_DUAL
+#define T360_DUAL 0
+#endif
+constexpr bool dual_copy(int ks) { return T360_DUAL != 0 && ks != 1; }
+template <int P, bool DUAL>
+struct Slot {
+  // copy B: the same bytes 4 further (odd dwords become 8-byte aligned) and half a bank row (32 dwords) apart,
+  // so that the A and B qwords of neighbouring lanes do not meet on the same banks
+  static constexpr int kCopyB = P * 1024 + 4 + 128;
+  static constexpr int kSlot = DUAL ? 2 * P * 1024 + 128 + 64 : P * 1024 + 64;
 };
+template <int RINGKB, int P, bool DUAL>
+struct Cls {
+  static constexpr int kFit = RINGKB * 1024 / Slot<P, DUAL>::kSlot;
+  static constexpr int K = kFit > kMaxSlots ? kMaxSlots : kFit;  // < 2: the class does not fit this ring
+};
+// smallest class that holds `pieces`
+#define T360_FOR_CLASS(pieces, F)   \
+  if ((pieces) <= 8) { F(8) }       \
+  else if ((pieces) <= 12) { F(12) } \
+  else { F(16) }
 
 // ---- per-pixel geometry -----------------------------------------------------------------------
 // KS = taps per axis: 1 nearest, 2 bilinear, 4 bicubic, 8 Lanczos4.  A stencil row is read as WIN 4-byte
@@ -73,32 +95,58 @@ struct PixelSetup {
   bool live[NPX];          // pixel inside the plane (partial tiles)
 };
 
-template <int NPX, int KS, int PMAX>
-__device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t* __restrict__ wpack, const TileDesc& t,
-                                            PixelSetup<NPX, KS>& s) {
-  constexpr int NW = Stencil<KS>::NW;
-  const int tid = threadIdx.x;
-  uint32_t words[4];
-  if (NPX == 4) {
-    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + t.tlut)[tid];
-    words[0] = v.x; words[1] = v.y; words[2] = v.z; words[3] = v.w;
+// What a workgroup fetches from its tile index alone, before (and in parallel with) the tile descriptor.
+struct TileFetch {
+  uint32_t words[4];  // pixel words of this lane (16x16 tiles: words[0])
+  uint32_t chunk[4];  // chunk entries of this lane in pieces wave, wave + 4, wave + 8, wave + 12
+  uint32_t rowdw;     // dword `lane` of the row table = row_base of box rows 2*lane and 2*lane + 1
+};
+
+template <int KS>
+__device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, int max_pieces) {
+  TileFetch f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (KS == 8) {
+    f.words[0] = pl.tlut[(size_t)tile * tile_words(KS) + tid];
+    f.words[1] = f.words[2] = f.words[3] = kWordDead;
   } else {
-    words[0] = pl.tlut[t.tlut + tid];
+    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)tile * tile_words(KS))[tid];
+    f.words[0] = v.x; f.words[1] = v.y; f.words[2] = v.z; f.words[3] = v.w;
   }
-  // row table: int16 per box row behind the tile's chunk table
-  const uint16_t* __restrict__ rowtab = reinterpret_cast<const uint16_t*>(pl.chunks + t.chunks + (int)t.pieces * kPieceChunks);
+  const uint32_t* __restrict__ tc = pl.chunks + (size_t)tile * tile_chunk_dwords(max_pieces);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int piece = wave + 4 * j;
+    f.chunk[j] = piece < max_pieces ? tc[piece * kPieceChunks + lane] : 0u;
+  }
+  f.rowdw = tc[max_pieces * kPieceChunks + lane];
+  return f;
+}
+
+// row_base of box row r out of the wave-distributed row table (lane r/2 holds rows r & ~1 and r | 1)
+__device__ __forceinline__ int row_base_of(uint32_t rowdw, int r) {
+  const int v = __builtin_amdgcn_ds_bpermute((r >> 1) << 2, (int)rowdw);
+  return (r & 1) ? (v >> 16) : (int)(int16_t)v;
+}
+
+template <int NPX, int KS, int P>
+__device__ __forceinline__ void load_pixels(const TileFetch& tf, const uint32_t* __restrict__ wpack, PixelSetup<NPX, KS>& s) {
+  constexpr int NW = Stencil<KS>::NW;
 #pragma unroll
   for (int p = 0; p < NPX; p++) {
-    const uint32_t e = words[p];
+    const uint32_t e = tf.words[p];
     s.live[p] = (e >> 31) == 0;
     const int x = e & 2047, row = s.live[p] ? (int)((e >> kWordRowShift) & 255) : 0;
     const int frac = (e >> kWordFracShift) & 1023;
     s.sh[p] = (uint32_t)(x & 3) * 8u;
 #pragma unroll
     for (int k = 0; k < KS; k++) {
-      const int off = s.live[p] ? (int)(int16_t)rowtab[row + k] * kStageChunk + x : 0;
+      const int off = row_base_of(tf.rowdw, (row + k) & (kBoxMaxRows - 1)) * kStageChunk + x;
       // KS == 1 reads the byte itself from copy A; otherwise the aligned qword of copy A or B that holds the window
-      s.addr[p][k] = KS == 1 ? (uint32_t)off : (uint32_t)((off & ~3) + ((off & 4) ? Ring<PMAX, true>::kCopyB : 0));
+      s.addr[p][k] = !s.live[p]    ? 0u
+                     : KS == 1      ? (uint32_t)off
+                     : dual_copy(KS) ? (uint32_t)((off & ~3) + ((off & 4) ? Slot<P, true>::kCopyB : 0))
+                                     : (uint32_t)(off & ~3);
     }
     s.hb[p] = 0;
     if (NW > 0) {
@@ -117,6 +165,21 @@ __device__ __forceinline__ void load_pixels(const TiledPlane& pl, const uint32_t
       }
       s.hb[p] = (int)wpack[(size_t)frac * Stencil<KS>::PACK + 2 * NW];
     }
+  }
+}
+
+// Make hipcc wait for its own (counted) loads HERE: every loaded value passes through an empty asm, so the
+// compiler-inserted s_waitcnt lands before it and not in front of the first use inside the frame loop, where it
+// would also drain the DMA ring.
+template <int NPX, int KS>
+__device__ __forceinline__ void pin_pixels(PixelSetup<NPX, KS>& s) {
+#pragma unroll
+  for (int p = 0; p < NPX; p++) {
+    asm volatile("" : "+v"(s.hb[p]), "+v"(s.sh[p]));
+#pragma unroll
+    for (int r = 0; r < KS; r++) asm volatile("" : "+v"(s.addr[p][r]));
+#pragma unroll
+    for (int r = 0; r < Stencil<KS>::NW; r++) asm volatile("" : "+v"(s.wh[p][r]), "+v"(s.wl[p][r]));
   }
 }
 
@@ -179,6 +242,16 @@ __device__ __forceinline__ int pixel_dots(const uint32_t (&p)[N], const uint32_t
 
 // dword / byte store at (wave-uniform base) + (32-bit lane offset): the SGPR-base form, so the per-frame
 // advance of the base is scalar arithmetic
+__device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // the value IS wave-uniform; make hipcc see it
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  return reinterpret_cast<uint8_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+#ifdef T360_INSTRUMENT
+#define T360_UNIFORM(p) uniform_ptr(p)  // the divergent trace branches of this build hide the uniformity from hipcc
+#else
+#define T360_UNIFORM(p) (p)
+#endif
 __device__ __forceinline__ void store_dword(uint8_t* base, uint32_t off, uint32_t v) {
   asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
@@ -193,11 +266,10 @@ __device__ __forceinline__ uint32_t sat_pk_u8(uint32_t two_i16) {
   return r;
 }
 
-// one frame of one tile: gather from the ring slot at byte SLOT of the LDS, write the output pixels.
-// GROUP = pixels whose LDS reads are in flight together.
+// one frame of one tile: gather from the ring slot at byte SLOT of the LDS; returns what the lane stores (the
+// store itself is deferred by one frame, see tile_waves()).  GROUP = pixels whose LDS reads are in flight together.
 template <int NPX, int KS, int GROUP, int SLOT>
-__device__ __forceinline__ void gather_store(const PixelSetup<NPX, KS>& s, const uint8_t* __restrict__ lds,
-                                             uint8_t* __restrict__ dbase, uint32_t doff, int dstride, bool dword_store) {
+__device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const uint8_t* __restrict__ lds, bool dword_store) {
   constexpr int G = GROUP < NPX ? GROUP : NPX;
   constexpr int ROWS = Stencil<KS>::ROWS, WIN = Stencil<KS>::WIN;
   int v[NPX];
@@ -216,7 +288,14 @@ __device__ __forceinline__ void gather_store(const PixelSetup<NPX, KS>& s, const
       for (int p = 0; p < G; p++)
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
-          win[p][r] = *reinterpret_cast<const uint64_t*>(lds + s.addr[p0 + p][r] + SLOT);
+          if (dual_copy(KS)) {
+            win[p][r] = *reinterpret_cast<const uint64_t*>(lds + s.addr[p0 + p][r] + SLOT);
+          } else {
+            // two aligned dwords (the slot base does not fit ds_read2_b32's 8-bit offsets: two ds_read_b32)
+            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT);
+            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT + 4);
+            win[p][r] = (uint64_t)d0 | ((uint64_t)d1 << 32);
+          }
           if (WIN == 2) ext[p][r] = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT + 8);
         }
       // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
@@ -256,26 +335,36 @@ __device__ __forceinline__ void gather_store(const PixelSetup<NPX, KS>& s, const
     else
       b = (uint32_t)v[0];
     // byte k of b is the pixel of column x = lane % W in row 4*band + k of the tile.
+    if (!dword_store) return b;  // partial tiles / unaligned destinations: four byte stores
+    // 4x4 byte transpose inside each quad of lanes (DPP quad broadcasts + v_perm), so that
+    // lane i of a quad owns row i, columns 4j..4j+3 -> one coalesced dword store per lane
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x00, 0xf, 0xf, true);  // quad_perm 0,0,0,0
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x55, 0xf, 0xf, true);  // 1,1,1,1
+    const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xaa, 0xf, 0xf, true);  // 2,2,2,2
+    const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xff, 0xf, 0xf, true);  // 3,3,3,3
+    const uint32_t i = threadIdx.x & 3;
+    const uint32_t sel_lo = 0x0c0c0000u | ((4u + i) << 8) | i;           // [b0.byte_i, b1.byte_i, 0, 0]
+    const uint32_t sel_hi = 0x00000c0cu | ((4u + i) << 24) | (i << 16);  // [0, 0, b2.byte_i, b3.byte_i]
+    return __builtin_amdgcn_perm(b1, b0, sel_lo) | __builtin_amdgcn_perm(b3, b2, sel_hi);
+  }
+  return (uint32_t)v[0];
+}
+
+// the deferred store of one frame's value
+template <int NPX, int KS>
+__device__ __forceinline__ void emit(const PixelSetup<NPX, KS>& s, uint32_t val, uint8_t* __restrict__ dbase, uint32_t doff,
+                                     int dstride, bool dword_store) {
+  dbase = T360_UNIFORM(dbase);
+  if (NPX == 4) {
     if (dword_store) {
-      // 4x4 byte transpose inside each quad of lanes (DPP quad broadcasts + v_perm), so that
-      // lane i of a quad owns row i, columns 4j..4j+3 -> one coalesced dword store per lane
-      const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x00, 0xf, 0xf, true);  // quad_perm 0,0,0,0
-      const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x55, 0xf, 0xf, true);  // 1,1,1,1
-      const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xaa, 0xf, 0xf, true);  // 2,2,2,2
-      const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0xff, 0xf, 0xf, true);  // 3,3,3,3
-      const uint32_t i = threadIdx.x & 3;
-      const uint32_t sel_lo = 0x0c0c0000u | ((4u + i) << 8) | i;           // [b0.byte_i, b1.byte_i, 0, 0]
-      const uint32_t sel_hi = 0x00000c0cu | ((4u + i) << 24) | (i << 16);  // [0, 0, b2.byte_i, b3.byte_i]
-      const uint32_t w = __builtin_amdgcn_perm(b1, b0, sel_lo) | __builtin_amdgcn_perm(b3, b2, sel_hi);
-      store_dword(dbase, doff, w);
+      store_dword(dbase, doff, val);
     } else {
-      // partial tiles / unaligned destinations only
 #pragma unroll
       for (int p = 0; p < NPX; p++)
-        if (s.live[p]) store_byte(dbase, doff + (uint32_t)(p * dstride), b >> (8 * p));
+        if (s.live[p]) store_byte(dbase, doff + (uint32_t)(p * dstride), val >> (8 * p));
     }
   } else {
-    if (s.live[0]) store_byte(dbase, doff, (uint32_t)v[0]);
+    if (s.live[0]) store_byte(dbase, doff, val);
   }
 }
 
@@ -303,22 +392,11 @@ __device__ __forceinline__ uint32_t out_pos(const TiledPlane& pl, const TileDesc
   return (uint32_t)oy * (uint32_t)pl.dstride + (uint32_t)ox;
 }
 
-// XCD-aware order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md "Workgroup dispatch");
-// give every XCD one contiguous range of the execution-ordered tile list so neighbouring tiles --
-// whose footprints overlap by the stencil halo -- share an L2.  Bijective for any n.
-__device__ __forceinline__ int xcd_contiguous(int b, int n) {
-  const int xcd = b & 7, k = b >> 3;
-  const int q = n >> 3, rem = n & 7;
-  return xcd * q + (xcd < rem ? xcd : rem) + k;
-}
-
-// ============================ loader / consumer split ==========================================
-// Workgroup = 5 waves: wave 4 is the LOADER, waves 0-3 are CONSUMERS (cdna_hip_programming.md 5.6).  The
-// loader's instruction stream is only address setup, global_load_lds_dwordx4 and counted vmcnt waits; the
-// consumers' frame loop is only barrier -> ds_read -> dot4 -> store.  They meet at ONE s_barrier per frame:
-//     loader  : wait until frame i has landed | BARRIER i | refill the slot frame i-1 used
-//     consumer:                                 BARRIER i | gather frame i from its slot, store
-// The loader's vmcnt stream holds nothing but its own in-order DMA loads, so the count is exact.
+// ============================ staging ==========================================================
+// Every wave of the workgroup moves a quarter of the tile's staged bytes (pieces w, w+4, ...) and gathers a
+// quarter of its pixels; the waves meet at ONE s_barrier per frame.  A workgroup of exactly 4 waves puts one
+// wave on each SIMD of the CU wherever the dispatcher starts, so workgroups pack the CU without fragmentation
+// (a 4+1 loader/consumer split measured 2.2 resident workgroups per CU where 4 fit: tools/ubench/residency_bench).
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction only takes an immediate):
 // a computed jump into a table of 8-byte entries {s_waitcnt vmcnt(k); s_branch out}.
@@ -347,29 +425,27 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #undef T360_W
 }
 
-// One copy of one frame of one tile, global -> LDS by DMA: nj x (64 lanes x 16 bytes), nj wave-uniform in
-// 1..16.  SGPR-base + 32-bit VGPR-offset addressing, so per frame only the scalar base changes; M0 (the LDS
-// destination) is written and stepped next to the instruction that uses it.  hipcc does not count these loads
+// A wave's share of one copy of one frame of one tile, global -> LDS by DMA: nj x (64 lanes x 16 bytes), nj
+// wave-uniform in 1..4; the wave's pieces are 4 KiB apart in LDS (wave w moves pieces w, w+4, w+8, ...).
+// SGPR-base + 32-bit VGPR-offset addressing, so per frame only the scalar base changes; M0 (the LDS destination)
+// is written and stepped next to the instruction that uses it.  hipcc does not count these loads
 // (cdna_hip_programming.md 5.7): completion is ours to track with wait_vmcnt().
-// The 16 {load; step M0 by an SGPR; nop} triples are 16 bytes each (8 + 4 + 4) and laid out back to back; a computed jump enters the
-// chain at triple 16-nj (Duff's device), so no per-frame decision tree.  Triple k moves PIECE 15-k: `off[k]`
-// must hold the source offset of piece 15-k, M0 starts at the last piece's destination and walks down.
-__device__ __forceinline__ void dma_frame_n(int nj, const uint8_t* frame_base, uint32_t lds_dst, const int (&off)[16]) {
-  const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(16 - nj)));
-  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * 1024u));
-#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %16\n\ts_sub_u32 m0, m0, %19\n\ts_nop 0\n\t"
+// The 4 {load; step M0 by an SGPR; nop} triples are 16 bytes each (8 + 4 + 4) and laid out back to back; a computed
+// jump enters the chain at triple 4-nj (Duff's device), so no per-frame decision tree.  Triple k moves the
+// wave's piece 3-k: `off[k]` must hold its source offset; M0 starts at the last piece's destination and walks down.
+__device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, uint32_t lds_dst, const int (&off)[4]) {
+  const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(4 - nj)));
+  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * 4096u));
+#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %4\n\ts_sub_u32 m0, m0, %7\n\ts_nop 0\n\t"
   asm volatile(
-      "s_mov_b32 m0, %17\n\t"
+      "s_mov_b32 m0, %5\n\t"
       "s_getpc_b64 vcc\n\t"
-      "s_add_u32 vcc_lo, vcc_lo, %18\n\t"
+      "s_add_u32 vcc_lo, vcc_lo, %6\n\t"
       "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
       "s_setpc_b64 vcc\n\t"
-      T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3) T360_DMA(4) T360_DMA(5) T360_DMA(6) T360_DMA(7)
-      T360_DMA(8) T360_DMA(9) T360_DMA(10) T360_DMA(11) T360_DMA(12) T360_DMA(13) T360_DMA(14) T360_DMA(15)
+      T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3)
       :
-      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]),
-        "v"(off[8]), "v"(off[9]), "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]),
-        "s"(frame_base), "s"(m0_start), "s"(skip), "s"(1024u)
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(frame_base), "s"(m0_start), "s"(skip), "s"(4096u)
       : "memory", "vcc", "scc");
 #undef T360_DMA
 }
@@ -379,65 +455,88 @@ __device__ __forceinline__ void frame_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int PMAX, int K, bool DUAL>
-__device__ __forceinline__ void loader_wave(const TiledPlane& pl, const TileDesc& t, uint32_t lds_base, int f0, int f1) {
-  using R = Ring<PMAX, DUAL>;
-  const int lane = threadIdx.x & 63;
-  const int nj = (int)t.pieces;  // 1..PMAX
-  // chunk q = lane + 64*j lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
-  // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
-  int goff[kMaxPieces];  // goff[k] = source offset of piece 15-k (dma_frame_n's order)
-#pragma unroll
-  for (int k = 0; k < kMaxPieces; k++) {
-    const int j = kMaxPieces - 1 - k;
-    goff[k] = 0;
-    if (j < nj && j < PMAX) {  // wave-uniform
-      const uint32_t e = pl.chunks[t.chunks + j * kPieceChunks + lane];
-      goff[k] = (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk;
-    }
-  }
-  auto issue = [&](int f, int slot) {
-    const uint8_t* base = pl.src + (size_t)f * pl.src_frame_bytes;
-    const uint32_t dst = lds_base + (uint32_t)(slot * R::kSlot);
-    dma_frame_n(nj, base, dst, goff);
-    if (DUAL) dma_frame_n(nj, base, dst + (uint32_t)R::kCopyB, goff);
-  };
-  const int per_frame = DUAL ? 2 * nj : nj;  // DMA instructions per frame
-  const int nf = f1 - f0;
-  for (int j = 0; j < K - 1 && j < nf; j++) issue(f0 + j, j);
-  int fill = (K - 1) % K;
-  for (int i = 0; i < nf; i++) {
-    // loads younger than frame i's: frames i+1 .. min(i+K-2, nf-1)
-    if (K == 2)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      wait_vmcnt(min(K - 2, nf - 1 - i) * per_frame);
-    frame_barrier();  // frame i is visible to the consumers; they have left frame i-1's slot
-    if (i + K - 1 < nf) issue(f0 + i + K - 1, fill);
-    fill = fill + 1 == K ? 0 : fill + 1;
+#ifdef T360_INSTRUMENT
+#define T360_DBG(a, bit) (((a).debug >> (bit)) & 1)
+// per-workgroup phase timestamps of the instrumented build (T360_TRACE=file; tools/trace_stats.py)
+__device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
+  if (a.trace && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    a.trace[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
   }
 }
+#define T360_MARK(a, slot) trace_mark(a, slot)
+#else
+#define T360_DBG(a, bit) 0
+#define T360_MARK(a, slot)
+#endif
 
-template <int NPX, int KS, int GROUP, int PMAX, int K>
-__device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t,
-                                               const uint8_t* __restrict__ lds, int f0, int f1) {
-  using R = Ring<PMAX, KS != 1>;
+// The four waves of a workgroup, one tile, frames f0..f1-1.  P = slot class, K = frames in the ring.
+// Timeline of a wave at frame i (slot i % K):
+//     wait until MY pieces of frame i have landed | BARRIER i | store frame i-1's pixels | refill the slot frame i-1
+//     used with my pieces of frame i+K-1 | gather frame i
+// The store is deferred past the barrier so that the wave's vmcnt stream, which now holds its DMA loads AND its
+// stores, has no store younger than the loads it is about to wait for: loads complete in order among themselves, so
+// "at most D operations outstanding", D = my loads younger than frame i's, implies frame i's pieces are done whatever
+// the (older) stores do.
+template <int NPX, int KS, int GROUP, int P, int K>
+__device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, const TileFetch& tf,
+                                           const uint8_t* __restrict__ lds, int f0, int f1) {
+  constexpr bool DUAL = dual_copy(KS);
+  using R = Slot<P, DUAL>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  (void)lane;
+  const int mine = ((int)t.pieces - wave + 3) >> 2;  // my pieces: wave, wave + 4, wave + 8, wave + 12 (0..4 of them)
+  // chunk q = lane + 64*piece lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
+  // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
+  int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4's order)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int j = 3 - k;
+    const uint32_t e = tf.chunk[j];
+    goff[k] = (j < mine && 4 * j < P) ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds + (uint32_t)wave * 1024u;
+  auto issue = [&](int f, int slot_bytes) {
+    if (mine <= 0) return;
+    const uint8_t* base = T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)f * pl.src_frame_bytes));
+    dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, goff);
+    if (DUAL && !T360_DBG(a, 5)) dma_frame_4(mine, base, lds_base + (uint32_t)(slot_bytes + R::kCopyB), goff);
+  };
+  const int per_frame = DUAL ? 2 * mine : mine;  // my DMA instructions per frame
+  const int nf = f1 - f0;
+  T360_MARK(a, 1);  // tile tables here
+  // weights first (they depend on the pixel words only), then the prologue DMA, then wait for both
   PixelSetup<NPX, KS> px;
-  load_pixels<NPX, KS, PMAX>(pl, a.wpack, t, px);
+  load_pixels<NPX, KS, P>(tf, a.wpack, px);
+#pragma unroll
+  for (int j = 0; j < K - 1; j++)
+    if (j < nf) issue(f0 + j, j * R::kSlot);
+  pin_pixels<NPX, KS>(px);
+  T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
   const uint32_t doff = out_pos<NPX>(pl, t, dword_store);
-  uint8_t* __restrict__ d = pl.dst + (size_t)f0 * pl.dst_frame_bytes;  // wave-uniform: the store uses SGPR base + VGPR offset
-  const int nf = f1 - f0;
+  uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);  // the store uses SGPR base + VGPR offset
+  uint32_t pending = 0;
   for (int i = 0; i < nf; i += K) {
-#define T360_STEP(S)                                                                             \
+#define T360_STEP(S)                                                                                       \
     if constexpr (S < K) if (i + S < nf) {                                                                 \
-      frame_barrier();                                                                           \
-      gather_store<NPX, KS, GROUP, S * R::kSlot>(px, lds, d, doff, pl.dstride, dword_store);     \
-      d += pl.dst_frame_bytes;                                                                   \
+      wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
+      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
+      if (i + S > 0) {                                                                                     \
+        emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                                      \
+        d += pl.dst_frame_bytes;                                                                           \
+      }                                                                                                    \
+      if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
+      if (!T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store);           \
+      if (i + S == 0) T360_MARK(a, 3);                                                                     \
+      if (i + S == 1) T360_MARK(a, 4);                                                                     \
     }
     T360_STEP(0) T360_STEP(1) T360_STEP(2) T360_STEP(3)
 #undef T360_STEP
   }
+  if (nf > 0) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
+  T360_MARK(a, 5);
 }
 
 // ---- tiles too large to stage: direct gather ---------------------------------------------------
@@ -446,30 +545,69 @@ __device__ __forceinline__ void consumer_waves(const TiledArgs& a, const TiledPl
 template <int KS>
 __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, int f0, int f1) {
   const int tid = threadIdx.x;
-  if (tid >= 256) return;
   const int ox = t.ox + (tid & 15), oy = t.oy + (tid >> 4);
   if (ox >= pl.dw || oy >= pl.dh) return;
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
-  for (int f = f0; f < f1; f++) {
-    const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
-    pl.dst[(size_t)f * pl.dst_frame_bytes + (size_t)oy * pl.dstride + ox] = (uint8_t)v;
+  uint8_t* __restrict__ d = pl.dst + (size_t)oy * pl.dstride + ox;
+  if constexpr (KS == 2 || KS == 4) {
+    // tap offsets and weights are the same for every frame: set up once, then two frames' loads in flight together
+    constexpr int H = KS / 2 - 1, KK = KS * KS;
+    int off[KK], w[KK];
+    const int16_t* __restrict__ wt = a.wtab + (size_t)e.frac * KK;
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const int yr = wrap_coord((int)e.iy - H + r, pl.sh);
+#pragma unroll
+      for (int c = 0; c < KS; c++) {
+        off[r * KS + c] = yr * pl.sstride + wrap_coord((int)e.ix - H + c, pl.sw);
+        w[r * KS + c] = wt[r * KS + c];
+      }
+    }
+    for (int f = f0; f < f1; f += 2) {
+      const uint8_t* __restrict__ s0 = pl.src + (size_t)f * pl.src_frame_bytes;
+      const uint8_t* __restrict__ s1 = s0 + (f + 1 < f1 ? pl.src_frame_bytes : 0);
+      int v0[KK], v1[KK];
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        v0[k] = s0[off[k]];
+        v1[k] = s1[off[k]];
+      }
+      int sum0 = 1 << (kCoefBits - 1), sum1 = sum0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        sum0 += v0[k] * w[k];
+        sum1 += v1[k] * w[k];
+      }
+      d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum0 >> kCoefBits);
+      if (f + 1 < f1) d[(size_t)(f + 1) * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum1 >> kCoefBits);
+    }
+  } else {
+    for (int f = f0; f < f1; f++) {
+      const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
+      d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)v;
+    }
   }
 }
 
-// Grid: x = padded direct tiles of all planes (started first: they are the slowest per pixel), then the
-// staged tiles of all planes; y = frame groups.
-template <int KS, int PMAX, int K>
-__global__ __launch_bounds__(320) void remap_tiled_kernel(TiledArgs a) {
-  constexpr int GROUP = 2;  // LDS reads in groups of 2 px: fewer VGPRs, one more workgroup per CU
+// Grid (1-D): the direct tiles' work items first (they are the slowest per pixel), then the staged tiles'.
+template <int KS, int RINGKB>
+__global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
+#ifndef T360_GROUP
+#define T360_GROUP 4
+#endif
+  constexpr int GROUP = T360_GROUP;  // pixels whose LDS reads are in flight together (4: one LDS round trip per frame)
+  constexpr bool DUAL = dual_copy(KS);
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
-  const int f0 = blockIdx.y * a.frames_per_block;
-  const int f1 = min(f0 + a.frames_per_block, a.nframes);
-  int b = blockIdx.x;
+  // Work items = (tile, frame group), numbered with the frame group fastest: the groups of one tile start within
+  // microseconds of each other on the same XCD, so the tile's tables come from HBM once and from L2 afterwards.
+  int id = blockIdx.x, b, g;
   // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
   // hipcc copy the whole argument block to scratch
   TiledPlane pl = a.plane[0];
-  if (b < a.direct_blocks) {
-    if (b >= a.total_direct) return;
+  if (id < a.direct_blocks) {
+    b = id / a.groups;
+    g = id - b * a.groups;
+    if (b >= a.total_direct || T360_DBG(a, 2)) return;
     if (a.nplanes > 1 && b >= pl.ndirect) {
       b -= pl.ndirect;
       pl = a.plane[1];
@@ -482,10 +620,25 @@ __global__ __launch_bounds__(320) void remap_tiled_kernel(TiledArgs a) {
         }
       }
     }
-    direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + b], f0, f1);
+    const int f0 = g * a.frames_per_block;
+    direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + b], f0, min(f0 + a.frames_per_block, a.nframes));
     return;
   }
-  b = xcd_contiguous(b - a.direct_blocks, a.total_tiles);  // direct_blocks is a multiple of 8: XCD = blockIdx.x % 8 still
+  {
+    // XCD-aware order: workgroup id runs on XCD id % 8 (MI355X_MICROARCH.md "Workgroup dispatch"; direct_blocks is a
+    // multiple of 8); every XCD owns one contiguous range of the execution-ordered tile list, so neighbouring tiles --
+    // whose footprints overlap by the stencil halo -- share an L2
+    id -= a.direct_blocks;
+    const int xcd = id & 7, k = id >> 3;
+    const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+    const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
+    const int t_local = k / a.groups;
+    if (t_local >= len) return;
+    b = start + t_local;
+    g = k - t_local * a.groups;
+  }
+  const int f0 = g * a.frames_per_block;
+  const int f1 = min(f0 + a.frames_per_block, a.nframes);
   if (a.nplanes > 1 && b >= pl.ntiles) {
     b -= pl.ntiles;
     pl = a.plane[1];
@@ -498,45 +651,71 @@ __global__ __launch_bounds__(320) void remap_tiled_kernel(TiledArgs a) {
       }
     }
   }
+  const TileFetch tf = fetch_tile<KS>(pl, b, a.max_pieces);  // independent of the descriptor: all in flight together
   const TileDesc t = pl.tiles[b];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wave >= kLoaderWave) {
-    loader_wave<PMAX, K, KS != 1>(pl, t, (uint32_t)(uintptr_t)lds, f0, f1);
-  } else if (KS == 8 || t.kind == kTileStaged16) {
-    consumer_waves<1, KS, GROUP, PMAX, K>(a, pl, t, lds, f0, f1);
+#ifdef T360_INSTRUMENT
+  if (a.trace && threadIdx.x == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const size_t wg = blockIdx.x;
+    a.trace[wg * 8 + 7] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    a.trace[wg * 8 + 6] = ((unsigned long long)(unsigned)t.kind << 32) | (unsigned)t.pieces;
+  }
+  T360_MARK(a, 0);  // tile descriptor here
+#endif
+  if (T360_DBG(a, 3) && t.kind == kTileStaged16) return;
+  if (T360_DBG(a, 4) && t.kind != kTileStaged16) return;
+  const int pieces = (int)t.pieces;
+  if (KS == 8 || t.kind == kTileStaged16) {
+#define T360_TILE1(P) \
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K>(a, pl, t, tf, lds, f0, f1);
+    T360_FOR_CLASS(pieces, T360_TILE1)
+#undef T360_TILE1
   } else {
-    consumer_waves<(KS == 8 ? 1 : 4), KS, GROUP, PMAX, K>(a, pl, t, lds, f0, f1);
+#define T360_TILE4(P)                                                        \
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2)                               \
+      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K>(a, pl, t, tf, lds, f0, f1);
+    T360_FOR_CLASS(pieces, T360_TILE4)
+#undef T360_TILE4
   }
 }
 
-template <int KS, int PMAX, int K>
+// largest tile (in pieces) the ring of RINGKB KiB can hold two frames of
+template <int RINGKB, bool DUAL>
+constexpr int max_pieces_of() {
+  return Cls<RINGKB, 16, DUAL>::K >= 2 ? 16 : Cls<RINGKB, 12, DUAL>::K >= 2 ? 12 : Cls<RINGKB, 8, DUAL>::K >= 2 ? 8 : 0;
+}
+
+template <int KS, int RINGKB>
 hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
-  constexpr int lds_bytes = K * Ring<PMAX, KS != 1>::kSlot;
+  constexpr int lds_bytes = RINGKB * 1024;
+  if (a.max_pieces > max_pieces_of<RINGKB, dual_copy(KS)>()) return hipErrorInvalidValue;
   if (lds_bytes > 64 * 1024) {
     // per device and cheap: not cached (handles may live on several devices of one process)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, PMAX, K>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, RINGKB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((remap_tiled_kernel<KS, PMAX, K>), dim3(a.direct_blocks + a.total_tiles, groups, 1), dim3(320),
+  const int per_xcd = (a.total_tiles + 7) / 8;
+  hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB>), dim3(a.direct_blocks + 8 * per_xcd * groups, 1, 1), dim3(256),
                      (size_t)lds_bytes, stream, a);
   return hipGetLastError();
 }
 
 template <int KS>
 hipError_t launch_ks(const TiledArgs& a, int groups, hipStream_t stream) {
-  if (a.max_pieces == 8 && a.ring_slots == 2) return launch_one<KS, 8, 2>(a, groups, stream);
-  if (a.max_pieces == 8 && a.ring_slots == 3) return launch_one<KS, 8, 3>(a, groups, stream);
-  if (a.max_pieces == 6 && a.ring_slots == 3) return launch_one<KS, 6, 3>(a, groups, stream);
-  if (a.max_pieces == 12 && a.ring_slots == 2) return launch_one<KS, 12, 2>(a, groups, stream);
+  if (a.ring_kb == 26) return launch_one<KS, 26>(a, groups, stream);  // 6 workgroups per CU
+  if (a.ring_kb == 31) return launch_one<KS, 31>(a, groups, stream);  // 5 workgroups per CU
+  if (a.ring_kb == 38) return launch_one<KS, 38>(a, groups, stream);  // 4 workgroups per CU
   return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-const char* remap_tiled_kernel_name(int ks, int max_pieces, int ring_slots) {
+const char* remap_tiled_kernel_name(int ks, int ring_kb) {
   static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d, %d>", ks, max_pieces, ring_slots);
+  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d>", ks, ring_kb);
   return buf;
 }
 

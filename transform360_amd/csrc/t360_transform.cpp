@@ -185,7 +185,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (hipEventCreateWithFlags(&lp_fork_, hipEventDisableTiming) != hipSuccess) return;
 #ifdef T360_INSTRUMENT
   // tuning switches of the instrumented build (tools/ab.sh); the shipped library reads no environment
-  if (const char* e = getenv("T360_RING_SLOTS")) ring_slots_ = atoi(e);
+  if (const char* e = getenv("T360_RING_KB")) ring_kb_ = atoi(e);
   if (const char* e = getenv("T360_MAX_PIECES")) max_pieces_ = atoi(e);
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
@@ -195,6 +195,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
   if (const char* e = getenv("T360_ROW_PAD")) plan_row_pad_ = atoi(e);
+  if (const char* e = getenv("T360_ROW_ALIGN")) plan_row_align_ = atoi(e);
   if (getenv("T360_NO_TILED")) use_tiled_ = false;
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
 #endif
@@ -890,13 +891,36 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
     fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
     fused.max_pieces = max_pieces_;
-    fused.ring_slots = ring_slots_;
+    fused.ring_kb = ring_kb_;
+#ifdef T360_INSTRUMENT
+    fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
+#endif
   };
   auto flush_fused = [&]() -> bool {
     if (fused.nplanes == 0) return true;
-    fused.direct_blocks = (fused.total_direct + 7) & ~7;
+    fused.groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+    fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;
+#ifdef T360_INSTRUMENT
+    t360::DeviceBuffer trace;
+    const char* trace_path = getenv("T360_TRACE");
+    const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * ((fused.total_tiles + 7) / 8) * fused.groups;
+    if (trace_path && trace.reserve(nwg * 64) && hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
+      fused.trace = trace.as<unsigned long long>();
+#endif
     const bool ok = check(launch_remap_tiled(fused, stream_), "tiled remap launch");
-    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.max_pieces, fused.ring_slots);
+#ifdef T360_INSTRUMENT
+    if (fused.trace) {
+      std::vector<unsigned long long> host(nwg * 8);
+      if (hipStreamSynchronize(stream_) == hipSuccess &&
+          hipMemcpy(host.data(), trace.as<void>(), nwg * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(trace_path, "wb")) {
+          fwrite(host.data(), 8, host.size(), f);
+          fclose(f);
+        }
+      }
+    }
+#endif
+    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.ring_kb);
     reset_fused();
     return ok;
   };
@@ -980,8 +1004,10 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
   o.max_pieces = max_pieces_;
   o.wide_pct = plan_wide_pct_;
   o.strip_pct = plan_strip_pct_;
-  o.band = plan_band_;
+  o.band = plan_band_ > 0 ? plan_band_ : 4;
+  o.raster = plan_band_ <= 0;
   o.row_pad = plan_row_pad_;
+  o.row_align = plan_row_align_;
   HostGatherPlan hp;
   if (!plan_gather(lut.data(), P.map_w, P.map_h, in_w, in_h, o, &hp)) return true;  // not plannable: general gather
   if (!p.plan.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||

@@ -130,12 +130,13 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  // LDS-tiled gather: staging budget per tile and copy (1 KiB pieces) and frames in flight per workgroup; the
-  // pair selects the kernel instantiation (8, 2: two 16 KiB slots = 32.9 KiB of LDS, 4 workgroups per CU)
-  int max_pieces_ = 8;
-  int ring_slots_ = 2;
-  int frames_per_block_ = 16;  // frames one workgroup of the tiled gather walks with one tile
-  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 4, plan_row_pad_ = 0;  // PlanOptions
+  // LDS-tiled gather: staging budget per tile and copy (1 KiB pieces) and LDS ring per workgroup (38 KiB: 4
+  // workgroups per CU; a tile of up to 4 / 6 / 8 pieces keeps 4 / 3 / 2 frames in flight)
+  int max_pieces_ = 16;
+  int ring_kb_ = 38;
+  int frames_per_block_ = 32;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
+                               // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
+  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 0, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
   bool use_fast_lowpass_ = true;
