@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- Mpix/s remapped on the BASELINE.json workload, with roofline and CPU baseline.
+"""bench.py -- Mpix/s remapped on the BASELINE.json workload, with roofline, verification and CPU baseline.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config 2|3|1|4]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): a synthetic
-stream of 3840x1920 8-bit yuv420p equirect frames -> 512-edge CUBEMAP_32 (1536x1024), bicubic,
-low-pass off.  Frames are counter-hash noise generated on the device and RESIDENT IN HBM before
-the timed region starts; one "step" is one pass of the hot path (all three planes) over one batch
-of F frames (default 64: 708 MB of input, far larger than the 256 MB Infinity Cache).
+With --gpus N > 1 and no launcher environment the script starts its N ranks itself (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU);
+under a launcher (RANK / WORLD_SIZE set) it is one rank.
 
-Multi-GPU (--gpus N under torch.distributed.run): whole frames are sharded across ranks --
-rank r owns frames r*F .. r*F+F-1 of every step (weak scaling, no data-path collective).  RCCL
-is used only outside the timed region: broadcast of the 112-byte context from rank 0 and
-all_gather of per-rank output checksums.
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): a synthetic stream of
+3840x1920 8-bit yuv420p equirect frames -> 512-edge CUBEMAP_32 (1536x1024), bicubic, low-pass off.  Frames are
+counter-hash noise generated on the device and RESIDENT IN HBM before the timed region starts; one "step" is one
+pass of the hot path (all three planes, ONE fused kernel launch) over one batch of F frames (default 64: 708 MB of
+input, far larger than the 256 MB Infinity Cache).
+
+Timing: W warm-up steps, then R = 5 repeats of EXACTLY K steps, each repeat bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over the ranks; the MEDIAN repeat is reported (box-to-box
+and run-to-run spread on the pool is a few percent).  With the driver's K = 20 that is 6 400 frames per rank.
+
+Multi-GPU: whole frames are sharded across ranks -- rank r owns frames r*F .. r*F+F-1 of every step (weak scaling,
+no data-path collective).  RCCL is used only outside the timed region: broadcast of the 112-byte context from
+rank 0, all_gather of per-rank output checksums.  A second record, "strong_cfg5", times BASELINE.json configs[4] as
+written: 64 frames in total, 64/N per rank.
 
 Rank 0 prints ONE JSON line:
-  value      = frames/s (whole job) x output luma pixels / 1e6          [Mpix/s]
-  roofline   = algorithmic bytes of the dominant kernel per launch / its average launch duration
-               (HIP events on the launch stream, inside the timed region) vs 8 TB/s HBM peak
-  cpu_baseline = the CPU oracle (restatement of the reference's OpenCV path, NOT linked OpenCV)
-               with the reference's threading structure, timed on this host on a bounded sample
+  value        = frames/s (whole job) x output luma pixels / 1e6                              [Mpix/s]
+  roofline     = algorithmic bytes of the step's kernel launch / its average duration (HIP events on the launch
+                 stream inside the timed region) vs the 8 TB/s HBM peak; the kernel name is what the library
+                 reports it launched; HBM traffic counters cannot be read inside a run: "traffic" is null here and
+                 the PMC-derived figure lives in profiles/
+  verified     = frames of the LAST timed step's output compared, all planes, with the CPU oracle
+  cpu_baseline = the CPU oracle (restatement of the reference's OpenCV path, NOT linked OpenCV) with the
+                 reference's threading structure, timed on this host on a bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REPEATS = 5
 
 
 def workload(config):
@@ -118,37 +131,79 @@ def cpu_baseline(wl, lin, lout, budget_s):
     }
 
 
+def verify_frames(wl, lin, lout, d_in, d_out, frames, seed_of):
+    """Output frames `frames` of the device buffers against per-plane oracle calls (bit-exact is the bar)."""
+    import numpy as np
+
+    from oracle import t360_oracle as O
+    from transform360_amd.abi import filter_defaults
+    from transform360_amd.handler import noise_bytes
+    ctx = filter_defaults(**wl["ov"])
+    o = O.Oracle(ctx, threads=max(1, min(32, os.cpu_count() or 1)))
+    for idx, k in ((0, 0), (1, 1)):
+        assert o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+    worst, differing = 0, 0
+    for j in frames:
+        fin = d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes].cpu().numpy()
+        # the device generator and its host restatement must agree, or the comparison proves nothing
+        assert np.array_equal(fin, noise_bytes(lin.frame_bytes, seed_of(j))), "input frame %d is not the synthetic stream" % j
+        fout = d_out[j * lout.frame_bytes:(j + 1) * lout.frame_bytes].cpu().numpy()
+        for p in range(len(lout.dims)):
+            want = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
+            assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
+            d = np.abs(lout.plane_view(fout, p).astype(np.int16) - want.astype(np.int16))
+            worst = max(worst, int(d.max()))
+            differing += int(np.count_nonzero(d))
+    o.close()
+    return {"frames": list(frames), "planes": len(lout.dims), "max_abs_diff": worst, "differing_pixels": differing,
+            "against": "CPU oracle (oracle/), per-plane calls on the same synthetic frames"}
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (BASELINE config 5: 64)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison (development sweeps only)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
 
     import numpy as np
     import torch
 
-    from transform360_amd import handler
+    from transform360_amd import _lib, handler
     from transform360_amd.abi import FrameTransformContext, config_output, filter_defaults
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the remap path)"
     # T360_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then
     # share devices and the few collectives around the path run on CPU tensors); the driver's runs use
     # nccl (= RCCL), one rank per GPU
     backend = os.environ.get("T360_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (T360_DIST_BACKEND=gloo rehearses the multi-rank "
+                         "path on fewer devices)" % (world, torch.cuda.device_count()))
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
@@ -160,6 +215,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    L = _lib.load()
+    build_flags = int(L.T360_buildFlags())
+    if build_flags and not os.environ.get("T360_BENCH_ALLOW_INSTRUMENTED"):
+        raise SystemExit("refusing to benchmark an instrumented library (%s): it reads tuning and wrong-pixel switches "
+                         "from the environment" % _lib.LIB_PATH)
 
     wl = workload(args.config)
     in_w, in_h = wl["in_w"], wl["in_h"]
@@ -185,21 +246,23 @@ def main():
     init_ms = (time.perf_counter() - t_init0) * 1e3
 
     # synthetic stream: this rank's frames of one step, resident in HBM
+    def seed_of(j):
+        return handler.frame_seed(rank * F + j)
+
     d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
     for j in range(F):
-        handler.fill_noise(d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], handler.frame_seed(rank * F + j))
+        handler.fill_noise(d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], seed_of(j))
     d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
     descs = t.plane_descs(lin, lout)
 
-    def step(timed_events=None):
-        # one call = all three planes of F frames; with the bicubic workload this is ONE fused
-        # launch of the DMA-ring gather kernel (plus the low-pass launches for config 3)
+    def step(n_frames, timed_events=None):
+        # one call = all three planes of n_frames frames; ONE fused launch of the tiled gather kernel
+        # (plus the low-pass launches for config 3)
         if timed_events is not None:
-            e0, e1 = timed_events
-            e0.record(stream)
-        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, F, descs)
+            timed_events[0].record(stream)
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n_frames, descs)
         if timed_events is not None:
-            e1.record(stream)
+            timed_events[1].record(stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,23 +270,57 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
-    luma_ms = [a.elapsed_time(b) for a, b in events]
+    def timed_run(n_frames, steps):
+        """REPEATS x (exactly `steps` steps between barriers); returns per-repeat (elapsed max over ranks, [launch ms])."""
+        out = []
+        for _ in range(REPEATS):
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step(n_frames, events[k])
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
+                el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                elapsed = float(el.item())
+            out.append((elapsed, [a.elapsed_time(b) for a, b in events]))
+        return out
 
-    # verification outside the timed region: per-rank checksum of the outputs, gathered on rank 0
+    for _ in range(args.warmup):
+        step(F)
+    runs = timed_run(F, args.steps)
+    elapsed, launch_ms = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    kernel_name = t.lastKernel()
+
+    # BASELINE configs[4] as written: 64 frames in total, frame-sharded -> 64 / N per rank (strong scaling)
+    strong = None
+    f5 = 64 // world
+    if args.config == 2 and f5 >= 1 and 64 % world == 0 and f5 <= F:
+        for _ in range(max(2, args.warmup)):
+            step(f5)
+        sruns = timed_run(f5, args.steps)
+        s_el = sorted(r[0] for r in sruns)[len(sruns) // 2]
+        strong = {"frames_total": 64, "frames_per_gpu": f5, "n_gpus": world, "scaling": "strong",
+                  "ms_per_step": round(s_el / args.steps * 1e3, 4),
+                  "value": round(64 * args.steps / s_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                  "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in sruns]}
+        step(F)  # d_out holds a full-batch result again for the verification below
+        torch.cuda.synchronize()
+
+    # verification outside the timed region: oracle comparison of frames of the last step + per-rank checksums
+    verified = None
+    if not args.no_verify:
+        frames = sorted({0, min(15, F - 1), min(16, F - 1), min(31, F - 1), min(32, F - 1), F - 1})
+        if args.config == 4:
+            frames = frames[:2]  # 12.6 Mpix Lanczos4 frames: seconds each on the host
+        verified = verify_frames(wl, lin, lout, d_in, d_out, frames, seed_of)
+        ok = torch.tensor([1 if verified["max_abs_diff"] == 0 else 0], dtype=torch.int64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verified["all_ranks_ok"] = bool(int(ok.item()))
     csum = torch.sum(d_out.view(-1).to(torch.int64)).reshape(1).to(coll_dev)
     if dist is not None:
         allc = [torch.zeros_like(csum) for _ in range(world)]
@@ -233,23 +330,18 @@ def main():
         checksums = [int(csum.item())]
 
     if rank == 0:
+        if verified is not None and not (verified["max_abs_diff"] == 0 and verified["all_ranks_ok"]):
+            print(json.dumps({"error": "output differs from the oracle: no throughput is reported", "verified": verified}))
+            raise SystemExit(1)
         frames_total = args.steps * F * world
         fps = frames_total / elapsed
         out_mpix = out_w * out_h / 1e6
         alg_frame = lin.payload_bytes() + lout.payload_bytes()
-        luma_alg = F * alg_frame   # the fused launch moves every plane of F frames
-        luma_avg_s = (sum(luma_ms) / len(luma_ms)) * 1e-3
-        traffic = None
-        if os.path.exists(args.traffic_file):
-            try:
-                with open(args.traffic_file) as f:
-                    tj = json.load(f)
-                if tj.get("config") == args.config and tj.get("frames") == F:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+        launch_alg = F * alg_frame   # the fused launch moves every plane of F frames
+        launch_avg_s = (sum(launch_ms) / len(launch_ms)) * 1e-3
+        plan = [t.planStats(0), t.planStats(1)]
         res = {
-            "metric": "Mpix/s remapped (4K equirect\u2192512-edge cubemap, bicubic)" if args.config == 2
+            "metric": "Mpix/s remapped (4K equirect→512-edge cubemap, bicubic)" if args.config == 2
                       else "Mpix/s remapped (%s)" % wl["name"],
             "value": round(fps * out_mpix, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,20 +352,27 @@ def main():
                        "in": "%dx%d" % (in_w, in_h), "out": "%dx%d" % (out_w, out_h),
                        "sharding": "whole frames per rank, no data-path collective", "input": "resident in HBM"},
             "fps": round(fps, 1),
+            "repeats": REPEATS, "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in runs],
+            "frames_timed_per_gpu": REPEATS * args.steps * F,
             "frac_of_hbm_roofline_whole_job": round(alg_frame * fps / (HBM_PEAK_BPS * world), 4),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "remap_tiled_dma_kernel<1,%d>: Y+U+V planes of %d frames per launch%s" % (
-                    {0: 1, 1: 2, 2: 4, 4: 8}.get(int(ctx.interpolation_alg), 4), F,
-                    " (+ the low-pass launches of the step)" if ctx.enable_low_pass_filter else ""),
-                "achieved": round(luma_alg / luma_avg_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
-                "frac": round(luma_alg / luma_avg_s / HBM_PEAK_BPS, 4),
-                "algorithmic_bytes_per_launch": luma_alg, "avg_launch_ms": round(luma_avg_s * 1e3, 4),
-                "traffic": traffic,
+                "kernel": "%s: Y+U+V planes of %d frames per launch%s" % (
+                    kernel_name, F, " (+ the low-pass launches of the step)" if ctx.enable_low_pass_filter else ""),
+                "achieved": round(launch_alg / launch_avg_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                "frac": round(launch_alg / launch_avg_s / HBM_PEAK_BPS, 4),
+                "algorithmic_bytes_per_launch": launch_alg, "avg_launch_ms": round(launch_avg_s * 1e3, 4),
+                "traffic": None,
             },
+            "verified": verified,
+            "library": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "build_flags": build_flags,
+                        "version": L.T360_version().decode()},
+            "gather_plan": plan,
             "init_ms": round(init_ms, 1),
             "output_checksums": checksums,
         }
+        if strong is not None:
+            res["strong_cfg5"] = strong
         if world == 1:
             # "achievable" HBM rate of this box for reference: a plain device-to-device copy (read + write)
             try:
