@@ -25,7 +25,7 @@ def build():
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs + [
             os.path.join(ROOT, "transform360_amd", "csrc", "t360_plan.h"),
             os.path.join(ROOT, "transform360_amd", "csrc", "t360_internal.h")]):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "transform360_amd", "csrc")] + srcs + ["-o", so])
     L = C.CDLL(so)
     L.t360_plan_sim.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]

@@ -43,7 +43,8 @@ struct TiledPlane {
   const uint32_t* chunks;   // chunk tables + row tables of the staged tiles
   const LutEntry* lut;      // absolute LUT (direct tiles)
   int ntiles;
-  int ndirect;
+  int ndirect;              // direct tiles: those of the upper half of the plane first
+  int ndirect_top;
   int dst_dword_ok;         // plane base, stride and frame distance are 4-byte aligned: dword stores
 };
 struct TiledArgs {
@@ -56,7 +57,7 @@ struct TiledArgs {
   int total_tiles;          // staged tiles of all planes
   int total_direct;         // direct tiles of all planes
   int groups;               // frame groups = ceil(nframes / frames_per_block): work items per tile
-  int direct_blocks;        // total_direct * groups rounded up to a multiple of 8 (keeps blockIdx.x % 8 = XCD for the rest)
+  int direct_blocks;        // work items reserved for direct tiles: 8 * groups * (most direct tiles of one pole of one plane)
   int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
   int ring_kb;              // LDS per workgroup in KiB: selects the kernel instantiation (38 or 50)
 #ifdef T360_INSTRUMENT

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <utility>
 
 namespace t360 {
 
@@ -115,20 +117,22 @@ class Planner {
     if (fetched > max_pos_) return;
     f->skew = 0;
     place(f);
-    if (opt_.row_search && opt_.row_align > 1 && f->feasible && opt_.ks != 1) {
-      // the skew whose modelled bank conflicts are fewest (the staircase of source rows under a row of output pixels
-      // climbs or descends depending on where the tile sits on its cube face)
-      int best = lds_cycles(*f), best_skew = 0;
-      for (int sk = 1; sk < opt_.row_align; sk++) {
-        f->skew = sk;
-        place(f);
-        if (!f->feasible) continue;
-        const int c = lds_cycles(*f);
-        if (c < best) best = c, best_skew = sk;
-      }
-      f->skew = best_skew;
+  }
+
+  // the skew whose modelled bank conflicts are fewest (the staircase of source rows under a row of output pixels
+  // climbs or descends depending on where the tile sits on its cube face); run on the tiles that are emitted
+  void choose_skew(Foot* f) const {
+    if (!(opt_.row_search && opt_.row_align > 1 && f->feasible && opt_.ks != 1)) return;
+    int best = lds_cycles(*f), best_skew = 0;
+    for (int sk = 1; sk < opt_.row_align; sk++) {
+      f->skew = sk;
       place(f);
+      if (!f->feasible) continue;
+      const int c = lds_cycles(*f);
+      if (c < best) best = c, best_skew = sk;
     }
+    f->skew = best_skew;
+    place(f);
   }
 
   // LDS placement of the box rows.  Every pixel looks its stencil rows up in the row table, so rows may sit anywhere
@@ -213,8 +217,9 @@ class Planner {
     int total = 0;
     const int npx = s.npx;
     for (int g = 0; g < 8; g++) {  // 8 groups of 32 lanes
-      for (int p = 0; p < npx; p++)
-        for (int k = 0; k < opt_.ks; k++)
+      // a sample of the reads is enough to rank placements: first / last pixel of the lane, first / last stencil row
+      for (int p = 0; p < npx; p += (npx > 1 ? npx - 1 : 1))
+        for (int k = 0; k < opt_.ks; k += (opt_.ks > 1 ? opt_.ks - 1 : 1))
           for (int acc = 0; acc < (dual ? 1 : 2); acc++) {
             int cnt[64];
             int addr_of[64][4];
@@ -250,7 +255,8 @@ class Planner {
     return total;
   }
 
-  void emit(const Foot& f, HostGatherPlan* out) const {
+  void emit(Foot& f, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
+    choose_skew(&f);
     TileDesc t{};
     t.ox = (int16_t)f.ox;
     t.oy = (int16_t)f.oy;
@@ -260,7 +266,7 @@ class Planner {
     PlanStats& st = out->stats;
     if (!f.feasible) {
       t.kind = kTileDirect16;
-      direct_.push_back(t);
+      direct->push_back(t);
       st.n_direct++;
       st.direct_pixels += (int64_t)(std::min(f.ox + s.w, dw_) - f.ox) * (std::min(f.oy + s.h, dh_) - f.oy);
       return;
@@ -360,90 +366,125 @@ class Planner {
     out->chunks.swap(chunks);
   }
 
+  // the tiles of one 128x32 output region, appended to `out` in execution order
+  void plan_region(int rx, int ry, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
+    const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
+    const bool wide_ok = !only16 && opt_.wide_pct > 0 && opt_.ks != 1;  // nearest has no halo to share
+    const bool strip_ok = !only16 && opt_.strip_pct > 0;
+    Foot strip[4], wide[2], sq[4], small;
+    const int ox = rx * 128, oy = ry * 32;
+    // squares first (always evaluated: they are the fallback), then the wider shapes
+    auto cost_sq = [&](int k, bool* all_staged) -> int64_t {
+      if (sq[k].empty) return 0;
+      if (sq[k].feasible) return (int64_t)sq[k].fetched;
+      *all_staged = false;
+      return (int64_t)1 << 40;
+    };
+    for (int k = 0; k < 4; k++) {
+      if (only16)
+        sq[k].empty = ox + 32 * k >= dw_ || oy >= dh_, sq[k].feasible = false;
+      else
+        footprint(ox + 32 * k, oy, kSquare, &sq[k]);
+    }
+    if (strip_ok) {
+      bool ok = true, sq_ok = true;
+      int64_t cs = 0, cq = 0;
+      for (int k = 0; k < 4; k++) {
+        footprint(ox, oy + 8 * k, kStrip, &strip[k]);
+        if (!strip[k].empty) {
+          ok = ok && strip[k].feasible;
+          cs += strip[k].fetched;
+        }
+        cq += cost_sq(k, &sq_ok);
+      }
+      if (ok && (!sq_ok || cs * 100 <= cq * opt_.strip_pct)) {
+        for (int k = 0; k < 4; k++)
+          if (!strip[k].empty) emit(strip[k], out, direct);
+        return;
+      }
+    }
+    for (int h = 0; h < 2; h++) {
+      if (wide_ok && !sq[2 * h].empty && !sq[2 * h + 1].empty) {
+        footprint(ox + 64 * h, oy, kWide, &wide[0]);
+        footprint(ox + 64 * h, oy + 16, kWide, &wide[1]);
+        const bool wf = (wide[0].empty || wide[0].feasible) && (wide[1].empty || wide[1].feasible) && !wide[0].empty;
+        bool sq_ok = true;
+        const int64_t cq = cost_sq(2 * h, &sq_ok) + cost_sq(2 * h + 1, &sq_ok);
+        const int64_t cw = (wide[0].empty ? 0 : wide[0].fetched) + (wide[1].empty ? 0 : wide[1].fetched);
+        if (wf && (!sq_ok || cw * 100 <= cq * opt_.wide_pct)) {
+          if (!wide[0].empty) emit(wide[0], out, direct);
+          if (!wide[1].empty) emit(wide[1], out, direct);
+          continue;
+        }
+      }
+      for (int k = 2 * h; k < 2 * h + 2; k++) {
+        if (sq[k].empty) continue;
+        if (sq[k].feasible) {
+          emit(sq[k], out, direct);
+          continue;
+        }
+        for (int qd = 0; qd < 4; qd++) {
+          footprint(ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, kSmall, &small);
+          if (!small.empty) emit(small, out, direct);  // staged 16x16 or direct
+        }
+      }
+    }
+  }
+
   bool run(HostGatherPlan* out) const {
+    const int regions_x = (dw_ + 127) / 128, regions_y = (dh_ + 31) / 32;
+    const int band = std::max(1, opt_.band);
+    // Emission order = execution order.  raster = false: region rows are walked in bands, column by column inside
+    // a band, so that vertically adjacent tiles -- whose footprints share the stencil halo and the rows a curved
+    // footprint adds -- run at the same time on the same XCD.
+    std::vector<std::pair<int, int>> regions;
+    for (int ry0 = 0; ry0 < regions_y; ry0 += band)
+      for (int rx = 0; rx < regions_x; rx++)
+        for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) regions.push_back({rx, ry});
+    // regions are independent: plan contiguous slices of the list on a few host threads, splice in order
+    const size_t n = regions.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, (n + 7) / 8}));
+    std::vector<HostGatherPlan> part(nthreads);
+    std::vector<std::vector<TileDesc>> part_direct(nthreads);
+    auto work = [&](size_t ti) {
+      const size_t lo = n * ti / nthreads, hi = n * (ti + 1) / nthreads;
+      for (size_t i = lo; i < hi; i++) plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
+    };
+    {
+      std::vector<std::thread> th;
+      for (size_t ti = 1; ti < nthreads; ti++) th.emplace_back(work, ti);
+      work(0);
+      for (auto& t : th) t.join();
+    }
     out->tiles.clear();
     out->tlut.clear();
     out->chunks.clear();
     out->stats = PlanStats();
-    direct_.clear();
-    const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
-    const bool wide_ok = !only16 && opt_.wide_pct > 0 && opt_.ks != 1;  // nearest has no halo to share
-    const bool strip_ok = !only16 && opt_.strip_pct > 0;
-    const int regions_x = (dw_ + 127) / 128, regions_y = (dh_ + 31) / 32;
-    const int band = std::max(1, opt_.band);
-    // Emission order = execution order.  Region rows are walked in bands, column by column inside a band, so
-    // that vertically adjacent tiles -- whose footprints share the stencil halo and the rows a curved footprint
-    // adds -- run at the same time on the same XCD and meet in its L2.
-    Foot strip[4], wide[4], sq[4], small;
-    for (int ry0 = 0; ry0 < regions_y; ry0 += band)
-      for (int rx = 0; rx < regions_x; rx++)
-        for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) {
-          const int ox = rx * 128, oy = ry * 32;
-          // squares first (always evaluated: they are the fallback), then the wider shapes
-          auto cost_sq = [&](int k, bool* all_staged) -> int64_t {
-            if (sq[k].empty) return 0;
-            if (sq[k].feasible) return (int64_t)sq[k].fetched;
-            *all_staged = false;
-            return (int64_t)1 << 40;
-          };
-          for (int k = 0; k < 4; k++) {
-            if (only16)
-              sq[k].empty = ox + 32 * k >= dw_ || oy >= dh_, sq[k].feasible = false;
-            else
-              footprint(ox + 32 * k, oy, kSquare, &sq[k]);
-          }
-          bool strips_chosen = false;
-          if (strip_ok) {
-            bool ok = true, sq_ok = true;
-            int64_t cs = 0, cq = 0;
-            for (int k = 0; k < 4; k++) {
-              footprint(ox, oy + 8 * k, kStrip, &strip[k]);
-              if (!strip[k].empty) {
-                ok = ok && strip[k].feasible;
-                cs += strip[k].fetched;
-              }
-              cq += cost_sq(k, &sq_ok);
-            }
-            if (ok && (!sq_ok || cs * 100 <= cq * opt_.strip_pct)) {
-              for (int k = 0; k < 4; k++)
-                if (!strip[k].empty) emit(strip[k], out);
-              strips_chosen = true;
-            }
-          }
-          if (strips_chosen) continue;
-          for (int h = 0; h < 2; h++) {
-            bool done = false;
-            if (wide_ok && !sq[2 * h].empty && !sq[2 * h + 1].empty) {
-              footprint(ox + 64 * h, oy, kWide, &wide[0]);
-              footprint(ox + 64 * h, oy + 16, kWide, &wide[1]);
-              const bool wf = (wide[0].empty || wide[0].feasible) && (wide[1].empty || wide[1].feasible) && !wide[0].empty;
-              bool sq_ok = true;
-              const int64_t cq = cost_sq(2 * h, &sq_ok) + cost_sq(2 * h + 1, &sq_ok);
-              const int64_t cw = (wide[0].empty ? 0 : wide[0].fetched) + (wide[1].empty ? 0 : wide[1].fetched);
-              if (wf && (!sq_ok || cw * 100 <= cq * opt_.wide_pct)) {
-                if (!wide[0].empty) emit(wide[0], out);
-                if (!wide[1].empty) emit(wide[1], out);
-                done = true;
-              }
-            }
-            if (done) continue;
-            for (int k = 2 * h; k < 2 * h + 2; k++) {
-              if (sq[k].empty) continue;
-              if (sq[k].feasible) {
-                emit(sq[k], out);
-                continue;
-              }
-              for (int qd = 0; qd < 4; qd++) {
-                footprint(ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, kSmall, &small);
-                if (!small.empty) emit(small, out);  // staged 16x16 or direct
-              }
-            }
-          }
-        }
+    std::vector<TileDesc> direct;
+    for (size_t ti = 0; ti < nthreads; ti++) {
+      const HostGatherPlan& p = part[ti];
+      out->tiles.insert(out->tiles.end(), p.tiles.begin(), p.tiles.end());
+      out->tlut.insert(out->tlut.end(), p.tlut.begin(), p.tlut.end());
+      out->chunks.insert(out->chunks.end(), p.chunks.begin(), p.chunks.end());
+      direct.insert(direct.end(), part_direct[ti].begin(), part_direct[ti].end());
+      PlanStats& a = out->stats;
+      const PlanStats& b = p.stats;
+      a.n_strip += b.n_strip; a.n_wide += b.n_wide; a.n_sq += b.n_sq; a.n_16 += b.n_16; a.n_direct += b.n_direct;
+      a.fetched_bytes += b.fetched_bytes; a.lds_bytes += b.lds_bytes; a.direct_pixels += b.direct_pixels;
+      a.lds_cycles_model += b.lds_cycles_model;
+      for (int i = 0; i < 33; i++) a.pieces_hist[i] += b.pieces_hist[i];
+    }
     if (opt_.raster) raster_order(out);
     out->ntiles = (int)out->tiles.size();
-    out->ndirect = (int)direct_.size();
-    out->tiles.insert(out->tiles.end(), direct_.begin(), direct_.end());
+    // direct tiles: upper half of the plane first (each pole's tiles go to one XCD, t360_remap_tiled.hip)
+    std::stable_sort(direct.begin(), direct.end(), [&](const TileDesc& x, const TileDesc& y) {
+      return (x.oy >= dh_ / 2) < (y.oy >= dh_ / 2);
+    });
+    out->ndirect = (int)direct.size();
+    out->ndirect_top = 0;
+    for (const TileDesc& t : direct) out->ndirect_top += t.oy < dh_ / 2 ? 1 : 0;
+    out->tiles.insert(out->tiles.end(), direct.begin(), direct.end());
     if (out->tlut.empty()) out->tlut.push_back(kWordDead);
     if (out->chunks.empty()) out->chunks.push_back(0);
     return out->tlut.size() < 0x7fffffffu && out->chunks.size() < 0x7fffffffu;
@@ -454,7 +495,6 @@ class Planner {
   int dw_, dh_, sw_, sh_;
   PlanOptions opt_;
   int lo_, hi_, max_pos_;
-  mutable std::vector<TileDesc> direct_;
 };
 
 }  // namespace

@@ -18,7 +18,7 @@ struct PlanOptions {
   int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
   int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
   int band = 4;          // raster = false: region rows walked column by column (execution order, see t360_plan.cpp)
-  bool raster = true;    // execution order = raster order of the tiles
+  bool raster = false;   // execution order = raster order of the tiles (measured: more HBM traffic than the banded order)
   int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
   int row_align = 8;     // LDS chunk position of a staged row == its source chunk column + skew * row, modulo this
                          // (1: rows packed back to back)
@@ -39,7 +39,7 @@ struct PlanStats {
 
 struct HostGatherPlan {
   std::vector<TileDesc> tiles;    // staged tiles in execution order, then the direct tiles
-  int ntiles = 0, ndirect = 0;
+  int ntiles = 0, ndirect = 0, ndirect_top = 0;  // direct tiles: those of the upper half of the plane first
   std::vector<uint32_t> tlut;     // pixel words, lane order (tile_word())
   std::vector<uint32_t> chunks;   // per staged tile 64 * pieces entries: chunk_entry()
   PlanStats stats;

@@ -37,6 +37,8 @@
 #include "t360_kernels.h"
 #include "t360_sample.h"
 
+#include <type_traits>
+
 namespace t360 {
 
 namespace {
@@ -550,37 +552,61 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
   uint8_t* __restrict__ d = pl.dst + (size_t)oy * pl.dstride + ox;
   if constexpr (KS == 2 || KS == 4) {
-    // tap offsets and weights are the same for every frame: set up once, then two frames' loads in flight together
+    // Row offsets and weights are the same for every frame: set up once.  A stencil row is ONE (unaligned) dword
+    // load unless it crosses the +-180 degree seam, and two frames' loads are in flight together: a quarter of the
+    // L2 requests of byte loads, which matters because these few tiles would otherwise issue a third of the
+    // kernel's L2 requests.
     constexpr int H = KS / 2 - 1, KK = KS * KS;
-    int off[KK], w[KK];
+    int roff[KS], w[KK];
     const int16_t* __restrict__ wt = a.wtab + (size_t)e.frac * KK;
+    const int x0 = (int)e.ix - H;
+    const bool contiguous = x0 >= 0 && x0 + 4 <= pl.sw;  // 4 bytes are read per row (bilinear uses the first 2)
 #pragma unroll
     for (int r = 0; r < KS; r++) {
-      const int yr = wrap_coord((int)e.iy - H + r, pl.sh);
+      roff[r] = wrap_coord((int)e.iy - H + r, pl.sh) * pl.sstride;
 #pragma unroll
-      for (int c = 0; c < KS; c++) {
-        off[r * KS + c] = yr * pl.sstride + wrap_coord((int)e.ix - H + c, pl.sw);
-        w[r * KS + c] = wt[r * KS + c];
-      }
+      for (int c = 0; c < KS; c++) w[r * KS + c] = wt[r * KS + c];
     }
-    for (int f = f0; f < f1; f += 2) {
-      const uint8_t* __restrict__ s0 = pl.src + (size_t)f * pl.src_frame_bytes;
-      const uint8_t* __restrict__ s1 = s0 + (f + 1 < f1 ? pl.src_frame_bytes : 0);
-      int v0[KK], v1[KK];
+    int xo[4];
 #pragma unroll
-      for (int k = 0; k < KK; k++) {
-        v0[k] = s0[off[k]];
-        v1[k] = s1[off[k]];
-      }
-      int sum0 = 1 << (kCoefBits - 1), sum1 = sum0;
+    for (int c = 0; c < 4; c++) xo[c] = wrap_coord(x0 + c, pl.sw);
+    // the frame loop once per case (not a branch per row: the loads of an iteration must all be in flight together)
+    auto frames = [&](auto contig) {
+      constexpr bool CONTIG = decltype(contig)::value;
+      for (int f = f0; f < f1; f += 2) {
+        const uint8_t* __restrict__ s0 = pl.src + (size_t)f * pl.src_frame_bytes;
+        const uint8_t* __restrict__ s1 = s0 + (f + 1 < f1 ? pl.src_frame_bytes : 0);
+        uint32_t v0[KS], v1[KS];
 #pragma unroll
-      for (int k = 0; k < KK; k++) {
-        sum0 += v0[k] * w[k];
-        sum1 += v1[k] * w[k];
+        for (int r = 0; r < KS; r++) {
+          if (CONTIG) {
+            __builtin_memcpy(&v0[r], s0 + roff[r] + x0, 4);
+            __builtin_memcpy(&v1[r], s1 + roff[r] + x0, 4);
+          } else {
+            v0[r] = v1[r] = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              v0[r] |= (uint32_t)s0[roff[r] + xo[c]] << (8 * c);
+              v1[r] |= (uint32_t)s1[roff[r] + xo[c]] << (8 * c);
+            }
+          }
+        }
+        int sum0 = 1 << (kCoefBits - 1), sum1 = sum0;
+#pragma unroll
+        for (int r = 0; r < KS; r++)
+#pragma unroll
+          for (int c = 0; c < KS; c++) {
+            sum0 += (int)((v0[r] >> (8 * c)) & 255u) * w[r * KS + c];
+            sum1 += (int)((v1[r] >> (8 * c)) & 255u) * w[r * KS + c];
+          }
+        d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum0 >> kCoefBits);
+        if (f + 1 < f1) d[(size_t)(f + 1) * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum1 >> kCoefBits);
       }
-      d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum0 >> kCoefBits);
-      if (f + 1 < f1) d[(size_t)(f + 1) * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum1 >> kCoefBits);
-    }
+    };
+    if (contiguous)
+      frames(std::true_type{});
+    else
+      frames(std::false_type{});
   } else {
     for (int f = f0; f < f1; f++) {
       const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
@@ -605,21 +631,19 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
   // hipcc copy the whole argument block to scratch
   TiledPlane pl = a.plane[0];
   if (id < a.direct_blocks) {
-    b = id / a.groups;
-    g = id - b * a.groups;
-    if (b >= a.total_direct || T360_DBG(a, 2)) return;
-    if (a.nplanes > 1 && b >= pl.ndirect) {
-      b -= pl.ndirect;
-      pl = a.plane[1];
-      if (a.nplanes > 2 && b >= pl.ndirect) {
-        b -= pl.ndirect;
-        pl = a.plane[2];
-        if (a.nplanes > 3 && b >= pl.ndirect) {
-          b -= pl.ndirect;
-          pl = a.plane[3];
-        }
-      }
-    }
+    // direct tiles: XCD x (= id % 8) serves pole (x & 1) of plane (x >> 1) -- the tiles around one pole read the same
+    // few source rows, which then come from HBM once and from that XCD's L2 for every other tile
+    const int xcd = id & 7, k = id >> 3;
+    const int t_local = k / a.groups;
+    g = k - t_local * a.groups;
+    const int plane = xcd >> 1, pole = xcd & 1;
+    if (plane >= a.nplanes || T360_DBG(a, 2)) return;
+    if (plane == 1) pl = a.plane[1];
+    if (plane == 2) pl = a.plane[2];
+    if (plane == 3) pl = a.plane[3];
+    const int count = pole ? pl.ndirect - pl.ndirect_top : pl.ndirect_top;
+    if (t_local >= count) return;
+    b = pole ? pl.ndirect_top + t_local : t_local;
     const int f0 = g * a.frames_per_block;
     direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + b], f0, min(f0 + a.frames_per_block, a.nframes));
     return;

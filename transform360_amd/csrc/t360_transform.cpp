@@ -899,7 +899,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   auto flush_fused = [&]() -> bool {
     if (fused.nplanes == 0) return true;
     fused.groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
-    fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;
+    int max_pole = 0;
+    for (int k = 0; k < fused.nplanes; k++)
+      max_pole = std::max(max_pole, std::max(fused.plane[k].ndirect_top, fused.plane[k].ndirect - fused.plane[k].ndirect_top));
+    fused.direct_blocks = 8 * max_pole * fused.groups;
 #ifdef T360_INSTRUMENT
     t360::DeviceBuffer trace;
     const char* trace_path = getenv("T360_TRACE");
@@ -957,6 +960,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       tp.lut = p.lut.as<LutEntry>();
       tp.ntiles = p.plan.ntiles;
       tp.ndirect = p.plan.ndirect;
+      tp.ndirect_top = p.plan.ndirect_top;
       tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
                         (!multi || (j.out_frame_bytes & 3) == 0);
       if (fused.nplanes == 4 && !flush_fused()) return false;
@@ -1024,6 +1028,7 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
     return false;
   p.plan.ntiles = hp.ntiles;
   p.plan.ndirect = hp.ndirect;
+  p.plan.ndirect_top = hp.ndirect_top;
   p.plan.stats = hp.stats;
   p.plan.valid = true;
   return true;

@@ -90,7 +90,7 @@ class VideoFrameTransform {
     // LDS-tiled gather: work list planned on the host at init (t360_plan.cpp)
     struct GatherPlan {
       bool valid = false;
-      int ntiles = 0, ndirect = 0;          // staged tiles first in `tiles`, the direct tiles behind them
+      int ntiles = 0, ndirect = 0, ndirect_top = 0;  // staged tiles first in `tiles`, the direct tiles behind them
       t360::DeviceBuffer tiles, tlut, chunks;
       t360::PlanStats stats;
     } plan;
@@ -136,7 +136,7 @@ class VideoFrameTransform {
   int ring_kb_ = 38;
   int frames_per_block_ = 32;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
-  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 0, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
+  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 4, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
   bool use_fast_lowpass_ = true;
