@@ -347,9 +347,20 @@ class Planner {
     const size_t n = out->tiles.size();
     std::vector<size_t> idx(n);
     for (size_t i = 0; i < n; i++) idx[i] = i;
+    // order 2: Z-order over 64x16 cells (neighbours in BOTH directions are a few list positions apart)
+    auto morton = [](unsigned x, unsigned y) {
+      uint64_t m = 0;
+      for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
+      return m;
+    };
+    const bool z = opt_.order == 2;
     std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
       const TileDesc& x = out->tiles[a];
       const TileDesc& y = out->tiles[b];
+      if (z) {
+        const uint64_t mx = morton((unsigned)x.ox >> 6, (unsigned)x.oy >> 4), my = morton((unsigned)y.ox >> 6, (unsigned)y.oy >> 4);
+        if (mx != my) return mx < my;
+      }
       return x.oy != y.oy ? x.oy < y.oy : x.ox < y.ox;
     });
     const size_t ws = (size_t)tile_words(opt_.ks), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
@@ -475,7 +486,7 @@ class Planner {
       a.lds_cycles_model += b.lds_cycles_model;
       for (int i = 0; i < 33; i++) a.pieces_hist[i] += b.pieces_hist[i];
     }
-    if (opt_.raster) raster_order(out);
+    if (opt_.order != 0) raster_order(out);
     out->ntiles = (int)out->tiles.size();
     // direct tiles: upper half of the plane first (each pole's tiles go to one XCD, t360_remap_tiled.hip)
     std::stable_sort(direct.begin(), direct.end(), [&](const TileDesc& x, const TileDesc& y) {

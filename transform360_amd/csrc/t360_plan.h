@@ -17,8 +17,8 @@ struct PlanOptions {
   int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces per copy (<= kMaxPieces)
   int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
   int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
-  int band = 4;          // raster = false: region rows walked column by column (execution order, see t360_plan.cpp)
-  bool raster = false;   // execution order = raster order of the tiles (measured: more HBM traffic than the banded order)
+  int band = 4;          // order 0: region rows walked column by column (execution order, see t360_plan.cpp)
+  int order = 2;         // execution order of the tiles: 0 bands of region rows (below), 1 raster, 2 Z-order of 64x16 cells
   int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
   int row_align = 8;     // LDS chunk position of a staged row == its source chunk column + skew * row, modulo this
                          // (1: rows packed back to back)

@@ -49,7 +49,10 @@ namespace {
 // class P >= p; its ring then holds K = min(4, ring / slot) frames.  Slot sizes are compile-time constants so
 // that the slot base is an immediate of the consumer's ds_read (the frame loop is unrolled over the K slots):
 // most tiles stage 4-8 KiB and keep 4 frames in the ring, the few large ones near the poles 2-3.
-constexpr int kMaxSlots = 4;
+#ifndef T360_MAX_SLOTS
+#define T360_MAX_SLOTS 3
+#endif
+constexpr int kMaxSlots = T360_MAX_SLOTS;
 // T360_DUAL: 1 = every chunk is staged twice (copy B four bytes further) so that each stencil-row window is ONE aligned
 // ds_read_b64; 0 = one copy, two aligned ds_read_b32 per window: twice the LDS read cycles, but half the LDS per frame in
 // flight.  The gather is bound by bytes in flight (HBM latency x bandwidth), not by LDS cycles: 0 measured faster.

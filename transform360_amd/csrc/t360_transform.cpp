@@ -1009,7 +1009,7 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
   o.wide_pct = plan_wide_pct_;
   o.strip_pct = plan_strip_pct_;
   o.band = plan_band_ > 0 ? plan_band_ : 4;
-  o.raster = plan_band_ <= 0;
+  o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
   o.row_pad = plan_row_pad_;
   o.row_align = plan_row_align_;
   HostGatherPlan hp;

@@ -134,9 +134,9 @@ class VideoFrameTransform {
   // workgroups per CU; a tile of up to 4 / 6 / 8 pieces keeps 4 / 3 / 2 frames in flight)
   int max_pieces_ = 16;
   int ring_kb_ = 38;
-  int frames_per_block_ = 32;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
+  int frames_per_block_ = 64;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
-  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = 4, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
+  int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
   bool use_fast_lowpass_ = true;
