@@ -1,0 +1,2 @@
+/* tests/c/avstub: see ../avfilter.h */
+#include "../avfilter.h"
