@@ -159,6 +159,37 @@ def verify_frames(wl, lin, lout, d_in, d_out, frames, seed_of):
             "against": "CPU oracle (oracle/), per-plane calls on the same synthetic frames"}
 
 
+def host_abi_rate(wl, lin, lout, ctx):
+    """The literal reference ABI: host (malloc'd) planes, one synchronous VideoFrameTransform_transformFramePlane call
+    per plane, as vf_transform360.c:368-397 does.  PCIe-bound by construction; reported next to the HBM-resident
+    number, never as `value`."""
+    import numpy as np
+
+    from transform360_amd import handler
+    rng = np.random.default_rng(1)
+    planes_in = [rng.integers(0, 256, (h, w), dtype=np.uint8) for (w, h) in lin.dims]
+    planes_out = [np.zeros((h, w), np.uint8) for (w, h) in lout.dims]
+    with handler.VideoFrameTransform(ctx) as t:
+        for idx, k in ((0, 0), (1, 1)):
+            assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+
+        def frame():
+            for k in range(len(planes_in)):
+                assert t.transformFramePlane(planes_in[k], planes_out[k], 1 if k else 0, k)
+        for _ in range(5):
+            frame()
+        n = 40
+        t0 = time.perf_counter()
+        for _ in range(n):
+            frame()
+        dt = (time.perf_counter() - t0) / n
+    nbytes = sum(p.nbytes for p in planes_in) + sum(p.nbytes for p in planes_out)
+    return {"frames_per_s": round(1 / dt, 1), "ms_per_frame": round(dt * 1e3, 4),
+            "Mpix_s": round(lout.dims[0][0] * lout.dims[0][1] / dt / 1e6, 1),
+            "pcie_GBps_in_plus_out": round(nbytes / dt / 1e9, 2),
+            "note": "host pointers, 3 synchronous calls per frame (the ffmpeg filter's pattern); PCIe-inclusive, not `value`"}
+
+
 def self_launch(args):
     """--gpus N without a launcher: start the N ranks ourselves."""
     with socket.socket() as s:
@@ -391,6 +422,8 @@ def main():
             except RuntimeError:
                 pass
         res["Mpix_s_in"] = round(fps * in_w * in_h / 1e6, 1)
+        if world == 1 and args.config == 2:
+            res["host_abi"] = host_abi_rate(wl, lin, lout, ctx)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)
         print(json.dumps(res))

@@ -226,7 +226,7 @@ inline void resize(const Mat& src, Mat& dst, Size dsize, double fx, double fy, i
   if (src.type() != CV_8U || dst.type() != CV_8U) throw Exception("shim: resize only for CV_8U");
   if (dst.cols != dsize.width || dst.rows != dsize.height) throw Exception("shim: resize needs a preallocated dst");
   if (!t360o_resize_area(src.data, src.cols, src.rows, src.step, dst.data, dst.cols, dst.rows, dst.step))
-    throw Exception("shim: cv::resize(INTER_AREA) enlargement is not restated");
+    throw Exception("shim: cv::resize(INTER_AREA) failed");
 }
 
 }  // namespace cv

@@ -402,12 +402,71 @@ static int resize_area_tab(int ssize, int dsize, double scale, DecimateAlpha* ta
   return k;
 }
 
+/* cv::resize(INTER_AREA) when either factor ENLARGES (scale < 1): OpenCV has true area interpolation only for
+ * scale_x >= 1 && scale_y >= 1 and otherwise "emulates it using some variant of bilinear interpolation"
+ * (resize.cpp, the general ksize = 2 path with area_mode coefficients): per destination column
+ *     sx = floor(dx * scale_x),  fx = (float)((dx + 1) - (sx + 1) * inv_scale_x),  fx = fx <= 0 ? 0 : fx - floor(fx)
+ * (same for rows), 11-bit fixed-point coefficients saturate_cast<short>(c * 2048), then the 8-bit bilinear kernels
+ *     HResizeLinear:  D = S[sx] * a0 + S[sx + 1] * a1      (dx < xmax;  D = S[sx] * 2048 beyond it)
+ *     VResizeLinear:  dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2
+ * with source rows clamped to the plane.  Restated from the published OpenCV 4.x algorithm; PARITY UNPINNED like
+ * the rest of this file (no OpenCV in this image). */
+static int resize_area_as_linear(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
+                                 size_t dstep) {
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
+  int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+  short* ialpha = (short*)malloc(sizeof(short) * (size_t)dw * 2);
+  int* hrow[2];
+  hrow[0] = (int*)malloc(sizeof(int) * (size_t)dw);
+  hrow[1] = (int*)malloc(sizeof(int) * (size_t)dw);
+  if (!xofs || !ialpha || !hrow[0] || !hrow[1]) {
+    free(xofs); free(ialpha); free(hrow[0]); free(hrow[1]);
+    return 0;
+  }
+  int xmax = dw;
+  for (int dx = 0; dx < dw; dx++) {
+    int sx = (int)floor(dx * scale_x);
+    float fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);
+    fx = fx <= 0 ? 0.f : fx - floorf(fx);
+    if (sx + 1 >= sw) { /* ksize2 = 1 */
+      if (dx < xmax) xmax = dx;
+      if (sx >= sw - 1) fx = 0, sx = sw - 1;
+    }
+    xofs[dx] = sx;
+    const float c0 = 1.f - fx, c1 = fx;
+    long a0 = lrintf(c0 * 2048.f), a1 = lrintf(c1 * 2048.f);
+    ialpha[2 * dx] = (short)(a0 > 32767 ? 32767 : a0);
+    ialpha[2 * dx + 1] = (short)(a1 > 32767 ? 32767 : a1);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    const int sy = (int)floor(dy * scale_y);
+    float fy = (float)((dy + 1) - (sy + 1) * inv_scale_y);
+    fy = fy <= 0 ? 0.f : fy - floorf(fy);
+    const int b0 = (int)lrintf((1.f - fy) * 2048.f), b1 = (int)lrintf(fy * 2048.f);
+    for (int k = 0; k < 2; k++) {
+      int r = sy + k; /* clip(sy - ksize2 + 1 + k, 0, sh) */
+      r = r >= 0 ? (r < sh ? r : sh - 1) : 0;
+      const uint8_t* S = src + (size_t)r * sstep;
+      int* D = hrow[k];
+      int dx = 0;
+      for (; dx < xmax; dx++) D[dx] = S[xofs[dx]] * ialpha[2 * dx] + S[xofs[dx] + 1] * ialpha[2 * dx + 1];
+      for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+    }
+    uint8_t* D = dst + (size_t)dy * dstep;
+    for (int dx = 0; dx < dw; dx++)
+      D[dx] = (uint8_t)((((b0 * (hrow[0][dx] >> 4)) >> 16) + ((b1 * (hrow[1][dx] >> 4)) >> 16) + 2) >> 2);
+  }
+  free(xofs); free(ialpha); free(hrow[0]); free(hrow[1]);
+  return 1;
+}
+
 int t360o_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh,
                       size_t dstep) {
   if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return 0;
   const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
   const double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
-  if (!(scale_x >= 1 && scale_y >= 1)) return 0; /* enlargement: not restated */
+  if (!(scale_x >= 1 && scale_y >= 1)) return resize_area_as_linear(src, sw, sh, sstep, dst, dw, dh, dstep);
   const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y); /* saturate_cast<int>(double) */
   const int fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
   if (fast && (size_t)iscale_x * dw == (size_t)sw && (size_t)iscale_y * dh == (size_t)sh) {

@@ -97,6 +97,14 @@ SUPERSAMPLE_FRAME_CASES = {
                         (1024, 512, 384, 256), 0, 0),
     "supersample_1p3x2p7_barrel": (dict(enable_low_pass_filter=0, width_scale_factor=1.3, height_scale_factor=2.7,
                                         output_layout=LAYOUT_BARREL), (1024, 512, 640, 256), 0, 0),
+    # factors below 1 (the filter accepts 0..10, vf_transform360.c:888-905): cv::resize(INTER_AREA) ENLARGES, which
+    # OpenCV emulates with its bilinear kernels
+    "subsample_0p5": (dict(enable_low_pass_filter=0, width_scale_factor=0.5, height_scale_factor=0.5),
+                      (1024, 512, 384, 256), 0, 0),
+    "subsample_0p7x0p4_linear": (dict(enable_low_pass_filter=0, width_scale_factor=0.7, height_scale_factor=0.4,
+                                      interpolation_alg=LINEAR), (1024, 512, 384, 256), 16, 32),
+    "mixed_1p5x0p6": (dict(enable_low_pass_filter=0, width_scale_factor=1.5, height_scale_factor=0.6),
+                      (1024, 512, 384, 256), 0, 0),
 }
 
 LAYOUT_FRAME_CASES = {

@@ -48,7 +48,7 @@ def test_verbatim_filter_compiles_and_links(tmp_path):
     (["cube_edge_length=260"], dict()),  # the option table's defaults: bicubic, low-pass on (5 x 1 segments); 260 -> 256
     (["cube_edge_length=256", "interpolation_alg=4", "enable_low_pass_filter=0"],
      dict(interpolation_alg=LANCZOS4, enable_low_pass_filter=0)),
-    (["cube_edge_length=128", "num_vertical_segments=15", "num_horizontal_segments=32", "fixed_yaw=30"],
+    (["cube_edge_length=128", "num_vertical_segments=15", "num_horizontal_segments=32", "yaw=30"],
      dict(num_vertical_segments=15, num_horizontal_segments=32, fixed_yaw=30.0)),
 ])
 def test_verbatim_filter_runs_and_matches_oracle(opts, ov, tmp_path, oracle_mod):

@@ -46,8 +46,8 @@ def draw(seed):
         ov["adjust_kernel"] = int(r.random() < 0.7)
         ov["kernel_height_scale_factor"] = float(np.float32(r.choice([0.5, 1.0, 2.0, 4.0])))
     if r.random() < 0.25:
-        ov["width_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 3.0, 1.5, 1.25])))
-        ov["height_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 1.5, 2.5])))
+        ov["width_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 3.0, 1.5, 1.25, 0.75, 0.5])))
+        ov["height_scale_factor"] = float(np.float32(r.choice([1.0, 2.0, 1.5, 2.5, 0.6])))
     # plane sizes: mostly 16-byte friendly (tiled DMA path), sometimes odd (general gather)
     if r.random() < 0.75:
         in_w, in_h = int(r.integers(8, 40)) * 16, int(r.integers(6, 30)) * 8

@@ -77,17 +77,16 @@ def test_map_bit_exact(name, T, oracle_mod, golden):
 
 
 def test_unsupported_request_is_refused_not_faked(T):
-    # INTER_AREA enlargement (scale factor < 1) is a different OpenCV code path that is not on the HIP
-    # path: the call must fail, not fall back to anything else
-    with T.VideoFrameTransform(filter_defaults(width_scale_factor=0.5, height_scale_factor=0.5)) as t:
-        ok = t.generateMapForPlane(1024, 512, 384, 256, 0)
-        src = dev(np.zeros((512, 1024), np.uint8))
-        dst = dev(np.zeros((256, 384), np.uint8))
-        _ready()
-        assert not (ok and t.transformFramePlane(src, dst, 0))
     from transform360_amd.abi import LAYOUT_N
     with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_N)) as t:
         assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
+    # a plane handed over with another output size than its map was generated for has no resize plan: refused
+    with T.VideoFrameTransform(filter_defaults(width_scale_factor=0.5, height_scale_factor=0.5)) as t:
+        assert t.generateMapForPlane(1024, 512, 384, 256, 0)
+        src = dev(np.zeros((512, 1024), np.uint8))
+        dst = dev(np.zeros((100, 200), np.uint8))
+        _ready()
+        assert not t.transformFramePlane(src, dst, 0)
 
 
 # ---------------------------------------------------------------- low-pass configuration

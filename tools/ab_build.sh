@@ -11,7 +11,7 @@ FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hi
 for f in t360_mapgen.hip t360_remap.hip t360_remap_tiled.hip t360_lowpass.hip t360_resize.hip; do
   /opt/rocm/bin/hipcc $FL -c $S/$f -o $O/${f%.hip}.o &
 done
-for f in t360_filtercfg.cpp t360_plan.cpp t360_transform.cpp t360_capi.cpp; do
+for f in t360_filtercfg.cpp t360_plan.cpp t360_hoststage.cpp t360_transform.cpp t360_capi.cpp; do
   /opt/rocm/bin/hipcc $FL -x hip -c $S/$f -o $O/${f%.cpp}.o &
 done
 wait

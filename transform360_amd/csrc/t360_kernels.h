@@ -107,6 +107,7 @@ struct ResizeArgs {
   uint8_t* dst;
   int64_t dst_frame_bytes;
   int dstride, dw, dh;
+  int linear, xmax;        // linear: the bilinear emulation of an enlarging INTER_AREA (tables re-used, see kernel)
   int iscale_x, iscale_y;  // > 0: integer factors (ResizeAreaFast); 0: table driven (ResizeArea)
   float inv_area;          // 1.f / (iscale_x * iscale_y)
   const int* xofs;         // [dw + 1] ranges into x_si / x_alpha

@@ -10,6 +10,10 @@
 //       buf = SUM_k S[si_k] * alpha_k   (float, table order, mul then add)
 //       sum = beta_0 * buf_0 + beta_1 * buf_1 + ...   (float, row order)
 //       out = sat_u8(rint(sum))
+//   either factor ENLARGING (scale < 1): OpenCV emulates INTER_AREA with its 8-bit bilinear kernels and area-mode
+//       coefficients (11-bit fixed point, host tables):
+//       D_r = S_r[sx] * a0 + S_r[sx + 1] * a1  (S_r[sx] * 2048 from column xmax on),  rows sy, sy + 1 clamped,
+//       out = (((b0 * (D_0 >> 4)) >> 16) + ((b1 * (D_1 >> 4)) >> 16) + 2) >> 2
 // One lane per output pixel; the work is a few source bytes per output byte, HBM/L2 streaming.
 #include <hip/hip_runtime.h>
 
@@ -30,7 +34,23 @@ __global__ __launch_bounds__(256) void resize_area_kernel(ResizeArgs a) {
   const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.z * a.src_frame_bytes;
   uint8_t* __restrict__ dst = a.dst + (size_t)blockIdx.z * a.dst_frame_bytes;
   int out;
-  if (a.iscale_x > 0) {
+  if (a.linear) {
+    // x tables: x_si = sx, xofs[2 dx], [2 dx + 1] = a0, a1; y tables: y_si = sy, yofs[2 dy], [2 dy + 1] = b0, b1
+    const int sx = a.x_si[dx], a0 = a.xofs[2 * dx], a1 = a.xofs[2 * dx + 1];
+    const int sy = a.y_si[dy], b0 = a.yofs[2 * dy], b1 = a.yofs[2 * dy + 1];
+    const int r0 = min(max(sy, 0), a.sh - 1), r1 = min(max(sy + 1, 0), a.sh - 1);
+    const uint8_t* __restrict__ S0 = src + (size_t)r0 * a.sstride;
+    const uint8_t* __restrict__ S1 = src + (size_t)r1 * a.sstride;
+    int d0, d1;
+    if (dx < a.xmax) {
+      d0 = S0[sx] * a0 + S0[sx + 1] * a1;
+      d1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    } else {
+      d0 = S0[sx] * 2048;
+      d1 = S1[sx] * 2048;
+    }
+    out = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+  } else if (a.iscale_x > 0) {
     int sum = 0;
     const uint8_t* __restrict__ S = src + (size_t)(dy * a.iscale_y) * a.sstride + (size_t)dx * a.iscale_x;
     for (int sy = 0; sy < a.iscale_y; sy++, S += a.sstride)

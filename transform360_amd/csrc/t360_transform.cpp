@@ -540,8 +540,45 @@ bool VideoFrameTransform::buildResizePlan(PlaneState& p) {
   const int sw = p.map_w, sh = p.map_h, dw = p.out_w, dh = p.out_h;
   if (dw <= 0 || dh <= 0) return true;
   const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
-  if (!(scale_x >= 1 && scale_y >= 1)) return true;  // enlargement: a different OpenCV path, refused at run time
   r.supported = true;
+  r.linear = false;
+  if (!(scale_x >= 1 && scale_y >= 1)) {
+    // an enlarging factor: OpenCV emulates INTER_AREA with its bilinear kernels (resize.cpp, ksize = 2, area_mode
+    // coefficients, 11-bit fixed point); tables in OpenCV's own float / double expressions
+    r.linear = true;
+    const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+    std::vector<int> xs((size_t)dw), xa((size_t)dw * 2), ys((size_t)dh), ya((size_t)dh * 2);
+    auto coef = [](float c) { long v = std::lrintf(c * 2048.f); return (int)(v > 32767 ? 32767 : v); };
+    r.xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+      int sx = (int)std::floor(dx * scale_x);
+      float fx = (float)((dx + 1) - (sx + 1) * inv_x);
+      fx = fx <= 0 ? 0.f : fx - std::floor(fx);
+      if (sx + 1 >= sw) {
+        r.xmax = std::min(r.xmax, dx);
+        if (sx >= sw - 1) fx = 0, sx = sw - 1;
+      }
+      xs[(size_t)dx] = sx;
+      xa[(size_t)2 * dx] = coef(1.f - fx);
+      xa[(size_t)2 * dx + 1] = coef(fx);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+      const int sy = (int)std::floor(dy * scale_y);
+      float fy = (float)((dy + 1) - (sy + 1) * inv_y);
+      fy = fy <= 0 ? 0.f : fy - std::floor(fy);
+      ys[(size_t)dy] = sy;
+      ya[(size_t)2 * dy] = coef(1.f - fy);
+      ya[(size_t)2 * dy + 1] = coef(fy);
+    }
+    auto up = [&](t360::DeviceBuffer& b, const void* src, size_t bytes) {
+      if (!b.reserve(bytes ? bytes : 4)) return check(hipErrorOutOfMemory, "hipMalloc(resize tables)");
+      return bytes == 0 || check(hipMemcpyAsync(b.as<void>(), src, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpy(resize tables)");
+    };
+    if (!up(r.x_si, xs.data(), xs.size() * 4) || !up(r.xofs, xa.data(), xa.size() * 4) || !up(r.y_si, ys.data(), ys.size() * 4) ||
+        !up(r.yofs, ya.data(), ya.size() * 4) || !r.x_alpha.reserve(4) || !r.y_alpha.reserve(4))
+      return false;
+    return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  }
   const int ix = (int)std::lrint(scale_x), iy = (int)std::lrint(scale_y);  // saturate_cast<int>(double)
   if (std::fabs(scale_x - ix) < DBL_EPSILON && std::fabs(scale_y - iy) < DBL_EPSILON && (int64_t)ix * dw == sw &&
       (int64_t)iy * dh == sh) {
@@ -770,8 +807,7 @@ bool VideoFrameTransform::runPlanesScaled(const PlaneJob* jobs, int njobs, int n
       return false;
     }
     if (!p.resize.supported) {
-      printf("Could not transform the plane %d. Error: INTER_AREA enlargement (scale factor < 1) is not implemented "
-             "on the HIP path\n", jobs[k].image_plane);
+      printf("Could not transform the plane %d. Error: no resize plan for this output size\n", jobs[k].image_plane);
       return false;
     }
     strides[(size_t)k] = (p.map_w + 255) & ~255;
@@ -807,6 +843,8 @@ bool VideoFrameTransform::runPlanesScaled(const PlaneJob* jobs, int njobs, int n
     a.dstride = jobs[k].out_stride;
     a.dw = jobs[k].out_w;
     a.dh = jobs[k].out_h;
+    a.linear = p.resize.linear ? 1 : 0;
+    a.xmax = p.resize.xmax;
     a.iscale_x = p.resize.iscale_x;
     a.iscale_y = p.resize.iscale_y;
     a.inv_area = p.resize.iscale_x > 0 ? 1.f / (float)(p.resize.iscale_x * p.resize.iscale_y) : 0.f;
@@ -1063,13 +1101,13 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   const uint8_t* d_in = inputData;
   int in_stride = inputWidthWithPadding;
   if (ik == PtrKind::Host) {
-    // stage over PCIe: rows packed at a 256-byte aligned pitch
+    // stage over PCIe (t360_hoststage.h: recurring buffers get pinned): rows packed at a 256-byte aligned pitch
     in_stride = (inputWidth + 255) & ~255;
-    if (!stage_in_.reserve((size_t)in_stride * inputHeight)) return check(hipErrorOutOfMemory, "hipMalloc(stage_in)");
-    if (!check(hipMemcpy2DAsync(stage_in_.as<void>(), (size_t)in_stride, inputData, (size_t)inputWidthWithPadding,
-                                (size_t)inputWidth, (size_t)inputHeight, hipMemcpyHostToDevice, stream_),
-               "hipMemcpy2DAsync(H2D)"))
-      return false;
+    if (!stage_in_.reserve((size_t)std::max(in_stride, inputWidthWithPadding) * inputHeight))
+      return check(hipErrorOutOfMemory, "hipMalloc(stage_in)");
+    if (!stager_.to_device(inputData, inputWidth, inputHeight, inputWidthWithPadding, stage_in_.as<uint8_t>(), in_stride, stream_,
+                           &in_stride))
+      return check(hipErrorUnknown, "host -> device staging");
     d_in = stage_in_.as<uint8_t>();
   }
   uint8_t* d_out = outputData;
@@ -1081,10 +1119,13 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
     const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
     if (barrel) {
       // BORDER_TRANSPARENT leaves destination bytes untouched: start from the caller's content
-      if (!check(hipMemcpy2DAsync(d_out, (size_t)out_stride, outputData, (size_t)outputWidthWithPadding,
-                                  (size_t)outputWidth, (size_t)outputHeight, hipMemcpyHostToDevice, stream_),
-                 "hipMemcpy2DAsync(H2D)"))
-        return false;
+      int used = out_stride;
+      if (!stage_out_.reserve((size_t)std::max(out_stride, outputWidthWithPadding) * outputHeight))
+        return check(hipErrorOutOfMemory, "hipMalloc(stage_out)");
+      d_out = stage_out_.as<uint8_t>();
+      if (!stager_.to_device(outputData, outputWidth, outputHeight, outputWidthWithPadding, d_out, out_stride, stream_, &used))
+        return check(hipErrorUnknown, "host -> device staging");
+      out_stride = used;
     }
   }
   (void)in_bytes;
@@ -1093,10 +1134,8 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
                      imagePlaneIndex};
   if (!runPlanes(&job, 1, 1)) return false;
   if (ok == PtrKind::Host) {
-    if (!check(hipMemcpy2DAsync(outputData, (size_t)outputWidthWithPadding, d_out, (size_t)out_stride,
-                                (size_t)outputWidth, (size_t)outputHeight, hipMemcpyDeviceToHost, stream_),
-               "hipMemcpy2DAsync(D2H)"))
-      return false;
+    if (!stager_.to_host(outputData, outputWidth, outputHeight, outputWidthWithPadding, d_out, out_stride, stream_))
+      return check(hipErrorUnknown, "device -> host staging");
   }
   // the reference call is synchronous: the output is complete when it returns
   return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");

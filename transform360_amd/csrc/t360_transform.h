@@ -14,6 +14,7 @@
 
 #include "Transform360/t360_device.h"
 #include "t360_filtercfg.h"
+#include "t360_hoststage.h"
 #include "t360_internal.h"
 #include "t360_devbuf.h"
 #include "t360_kernels.h"
@@ -72,8 +73,8 @@ class VideoFrameTransform {
     t360::DeviceBuffer col_tab, row_tab;           // per-column / per-row libm values (MapGenParams)
     // INTER_AREA shrink map_w x map_h -> out_w x out_h (only when the scale factors are not 1)
     struct ResizePlan {
-      bool needed = false, supported = false;
-      int iscale_x = 0, iscale_y = 0;
+      bool needed = false, supported = false, linear = false;
+      int iscale_x = 0, iscale_y = 0, xmax = 0;
       t360::DeviceBuffer xofs, x_si, x_alpha, yofs, y_si, y_alpha;
     } resize;
     // low-pass
@@ -142,5 +143,6 @@ class VideoFrameTransform {
   bool use_fast_lowpass_ = true;
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
-  t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path
+  t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path: device side
+  t360::HostStager stager_;                  // ... registration cache of the caller's recurring buffers
 };
