@@ -422,7 +422,7 @@ def main():
             except RuntimeError:
                 pass
         res["Mpix_s_in"] = round(fps * in_w * in_h / 1e6, 1)
-        if world == 1 and args.config == 2:
+        if world == 1 and args.config == 2 and not os.environ.get("T360_TRACE"):  # (a trace run keeps its last launch)
             res["host_abi"] = host_abi_rate(wl, lin, lout, ctx)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)

@@ -240,10 +240,11 @@ def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
 # runs of ring geometries and plan options; every one of those switches must leave the pixels alone.  It is a second
 # library, so it runs in a child process (tests/run_variants.py) with T360_LIB pointing at it.
 VARIANTS = [
-    {"T360_RING_KB": "31", "T360_MAX_PIECES": "12"}, {"T360_RING_KB": "26", "T360_MAX_PIECES": "12"}, {"T360_MAX_PIECES": "8"}, {"T360_MAX_PIECES": "4"},
+    {"T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "12"}, {"T360_WAVES": "4", "T360_RING_KB": "26", "T360_MAX_PIECES": "12"},
+    {"T360_MAX_PIECES": "8"}, {"T360_MAX_PIECES": "4"}, {"T360_WAVES": "4", "T360_RING_KB": "38", "T360_MAX_PIECES": "16"},
     {"T360_ROW_ALIGN": "1"}, {"T360_ROW_ALIGN": "4"}, {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"},
     {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
-    {"T360_FRAMES_PER_BLOCK": "3", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+    {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
 ]
 
 
@@ -266,7 +267,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
     from transform360_amd import _lib
     assert _lib.load().T360_buildFlags() == 0
     # a switch of the instrumented build must be inert here: same kernel instantiation as without it
-    monkeypatch.setenv("T360_RING_KB", "26")
+    monkeypatch.setenv("T360_RING_KB", "50")
     monkeypatch.setenv("T360_NO_TILED", "1")
     import torch
     with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
@@ -275,7 +276,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
         dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
         _ready()
         assert t.transformFramePlane(src, dst, 0)
-        assert t.lastKernel() == "remap_tiled_kernel<4, 38>"
+        assert t.lastKernel() == "remap_tiled_kernel<4, 76, 8>"
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)
@@ -351,6 +352,47 @@ def test_config4_batch_full_size_all_planes(T, oracle_mod):
 def test_bilinear_batch_full_size_all_planes(T, oracle_mod):
     _batch_case(T, oracle_mod, dict(interpolation_alg=LINEAR, enable_low_pass_filter=0), n=17,
                 dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
+
+
+def test_batch_mixing_scaled_and_unscaled_planes(T, oracle_mod):
+    """A scale factor can round one plane's map to a different size and leave the other's alone (1000 -> 1001 but
+    500 -> 500): the batch call must take both branches."""
+    import torch
+    from transform360_amd import _lib
+    ctx = filter_defaults(enable_low_pass_filter=0, width_scale_factor=1.0006, height_scale_factor=1.0)
+    o = oracle_mod.Oracle(ctx, threads=4)
+    dims = [(2048, 1024, 1000, 512), (1024, 512, 500, 256)]
+    n_frames = 2
+    in_bytes = sum(d[0] * d[1] for d in dims)
+    out_bytes = sum(d[2] * d[3] for d in dims)
+    d_in = torch.empty(n_frames * in_bytes, dtype=torch.uint8, device="cuda")
+    T.fill_noise(d_in, 0xABCD)
+    d_out = torch.zeros(n_frames * out_bytes, dtype=torch.uint8, device="cuda")
+    descs = (_lib.T360PlaneDesc * 2)()
+    io = oo = 0
+    for k, (iw, ih, ow, oh) in enumerate(dims):
+        descs[k] = _lib.T360PlaneDesc(in_offset=io, out_offset=oo, in_stride=iw, out_stride=ow, in_width=iw, in_height=ih,
+                                      out_width=ow, out_height=oh, map_index=k)
+        io += iw * ih
+        oo += ow * oh
+    with T.VideoFrameTransform(ctx) as t:
+        for k, d in enumerate(dims):
+            assert t.generateMapForPlane(*d, k) and o.generateMapForPlane(*d, k)
+        assert t.map(0).shape[1] == 1001 and t.map(1).shape[1] == 500  # one plane resizes, the other does not
+        assert t.setStream(torch.cuda.current_stream())
+        assert t.transformFrames(d_in, in_bytes, d_out, out_bytes, n_frames, descs)
+        assert t.synchronize()
+    h_in, h_out = d_in.cpu().numpy(), d_out.cpu().numpy()
+    for f in range(n_frames):
+        io = oo = 0
+        for k, (iw, ih, ow, oh) in enumerate(dims):
+            src = h_in[f * in_bytes + io:][:iw * ih].reshape(ih, iw)
+            want = np.zeros((oh, ow), np.uint8)
+            assert o.transformFramePlane(src, want, k, k)
+            got = h_out[f * out_bytes + oo:][:ow * oh].reshape(oh, ow)
+            assert np.array_equal(got, want), (f, k)
+            io += iw * ih
+            oo += ow * oh
 
 
 def test_five_planes_in_one_call(T, oracle_mod):

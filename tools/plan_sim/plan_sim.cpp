@@ -18,11 +18,12 @@ extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, 
   o.row_search = (row_pad >> 16) != 0;
   o.model_b_shift = unused;
   o.model_stats = true;
+  o.waves = (row_pad >> 24) ? 8 : 4;
   t360::HostGatherPlan plan;
   if (!t360::plan_gather(lut, dw, dh, sw, sh, o, &plan)) return 0;
   const t360::PlanStats& s = plan.stats;
-  stats[0] = s.n_strip; stats[1] = s.n_wide; stats[2] = s.n_sq; stats[3] = s.n_16; stats[4] = s.n_direct;
-  stats[5] = s.fetched_bytes; stats[6] = s.lds_bytes; stats[7] = s.direct_pixels; stats[8] = s.lds_cycles_model;
+  stats[0] = s.n_strip + s.n_wide128 * 2; stats[1] = s.n_wide; stats[2] = s.n_sq; stats[3] = s.n_16; stats[4] = s.n_direct;
+  stats[5] = s.fetched_bytes; stats[6] = s.lds_bytes; stats[7] = s.direct_pixels; stats[8] = s.line_bytes;
   stats[9] = (long long)plan.chunks.size() * 4; stats[10] = (long long)plan.tlut.size() * 4;
   int maxp = 0;
   for (int i = 0; i < plan.ntiles; i++) maxp = plan.tiles[i].pieces > maxp ? plan.tiles[i].pieces : maxp;

@@ -85,11 +85,11 @@ def main():
                     ntile = st[0] + st[1] + st[2] + st[3]
                     hist = {i: st[12 + i] for i in range(33) if st[12 + i]}
                     print("bshift %d pieces %2d wide %3d strip %3d pad %d: strips %d wide %d sq %d s16 %d direct %d (%d px) | fetched %.2f MB = %.3fx "
-                          "src | LDS %.2f MB (%.3fx fetched) | max pieces %d | model %.2f LDS cycles per 32-lane read "
+                          "src | LDS %.2f MB (%.3fx fetched) | max pieces %d | lines %.3fx src "
                           "| tables %.1f+%.1f MB" % (
                               bs, pieces, wide, strip, pm, st[0], st[1], st[2], st[3], st[4], st[7], st[5] / 1e6, st[5] / src,
                               st[6] / 1e6, st[6] / max(st[5], 1), st[11],
-                              st[8] / max(1, ((st[0] + st[1] + st[2]) * 32 + st[3] * 8) * ks * 2), st[9] / 1e6, st[10] / 1e6))
+                              st[8] / src, st[9] / 1e6, st[10] / 1e6))
                     print("   tile sizes (pieces: tiles):", hist)
 
 

@@ -86,6 +86,7 @@ enum : int {
                       // source footprint spans a quadrant of longitudes)
   kTileStrip128 = 3,  // 128x8 output px, 4 px per lane (2 bands): ~330-byte source row fragments
   kTileWide64 = 4,    // 64x16 output px, 4 px per lane (4 bands)
+  kTileWide128 = 5,   // 128x16 output px, 4 px per lane on 512 lanes (4 bands): workgroups of 8 waves only
 };
 enum : int {
   kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
@@ -94,7 +95,7 @@ enum : int {
 
 constexpr int kStageChunk = 16;   // bytes per staged chunk (one dwordx4 per DMA lane)
 constexpr int kPieceChunks = 64;  // chunks per DMA instruction (one per lane): a 1 KiB "piece"
-constexpr int kMaxPieces = 16;    // pieces of a tile's staged region (each of the 4 waves moves up to 4)
+constexpr int kMaxPieces = 32;    // pieces of a tile's staged region (each wave of the workgroup moves up to 4)
 
 // One unit of gather work.  The staged region of a tile is NOT a bounding box: the planner lists exactly the
 // 16-byte source chunks the tile's stencils touch (the footprint of an output tile in the equirect source is a
@@ -122,10 +123,11 @@ static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 //
 // Per-tile tables live at FIXED strides, so a workgroup can fetch them from its tile index alone, in parallel with
 // the descriptor (one memory round trip less in every workgroup's prologue):
-//   pixel words   tlut   + tile * tile_words(ks)           (a uint4 per lane; 16x16 tiles use its first word)
+//   pixel words   tlut   + tile * tile_words(ks, waves)    (a uint4 per lane; 16x16 tiles use its first word)
 //   chunk table   chunks + tile * tile_chunk_dwords(max_pieces):  64 * max_pieces chunk entries (the first
 //                 64 * pieces are meaningful), then the row table: 64 dwords = 128 int16
-constexpr int tile_words(int ks) { return ks == 8 ? 256 : 1024; }  // Lanczos4 plans hold 16x16 tiles only
+// pixel words per tile slot: a uint4 per lane (Lanczos4 plans hold 16x16 tiles only: one word per lane)
+constexpr int tile_words(int ks, int waves) { return ks == 8 ? 256 : 256 * waves; }
 constexpr int tile_chunk_dwords(int max_pieces) { return max_pieces * 64 + 64; }
 constexpr uint32_t kWordDead = 0x80000000u;
 constexpr int kWordRowShift = 11, kWordFracShift = 19;

@@ -57,9 +57,12 @@ struct TiledArgs {
   int total_tiles;          // staged tiles of all planes
   int total_direct;         // direct tiles of all planes
   int groups;               // frame groups = ceil(nframes / frames_per_block): work items per tile
+  int tail_percent;         // the last tail_percent % of every XCD's tiles use runs of tail_frames frames instead
+  int tail_frames, tail_groups;
   int direct_blocks;        // work items reserved for direct tiles: 8 * groups * (most direct tiles of one pole of one plane)
   int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
-  int ring_kb;              // LDS per workgroup in KiB: selects the kernel instantiation (38 or 50)
+  int ring_kb;              // LDS per workgroup in KiB and waves per workgroup (4 or 8): select the kernel instantiation
+  int waves;
 #ifdef T360_INSTRUMENT
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
                             // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B
@@ -71,7 +74,7 @@ struct TiledArgs {
 // Every plane's source must be 16-byte friendly (base, stride, frame distance, width).
 hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream);
 // the instantiation launch_remap_tiled() picks for these parameters (reporting)
-const char* remap_tiled_kernel_name(int ks, int ring_kb);
+const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves);
 
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {

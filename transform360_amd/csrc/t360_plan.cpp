@@ -1,7 +1,7 @@
 // t360_plan.cpp -- init-time planning of the LDS-tiled gather (host side, no HIP).
 //
 // The output plane is cut into tiles of 256 lanes x NPX pixels (128x8, 64x16 or 32x32 px with 4 px per lane;
-// 16x16 px with 1 px per lane near the poles).  For every tile the planner derives from the sample LUT
+// 16x16 px with 1 px per lane near the poles) and, for workgroups of 8 waves, 128x16 px tiles of 512 lanes.  For every tile the planner derives from the sample LUT
 //   * the FOOTPRINT: the set of 16-byte source chunks the tile's stencils touch.  In the equirect source the
 //     footprint of a cube-face tile is a curved band (an annular sector on the polar faces); its bounding box
 //     would stage up to 2.6x the bytes that are used, so the footprint is kept exact, row by row;
@@ -28,12 +28,13 @@ namespace t360 {
 namespace {
 
 struct TileShape {
-  int kind, w, h, npx;
+  int kind, w, h, npx, lanes;
 };
-constexpr TileShape kStrip{kTileStrip128, 128, 8, 4};
-constexpr TileShape kWide{kTileWide64, 64, 16, 4};
-constexpr TileShape kSquare{kTileStaged32, 32, 32, 4};
-constexpr TileShape kSmall{kTileStaged16, 16, 16, 1};
+constexpr TileShape kStrip{kTileStrip128, 128, 8, 4, 256};
+constexpr TileShape kWide{kTileWide64, 64, 16, 4, 256};
+constexpr TileShape kSquare{kTileStaged32, 32, 32, 4, 256};
+constexpr TileShape kSmall{kTileStaged16, 16, 16, 1, 256};
+constexpr TileShape kWide128{kTileWide128, 128, 16, 4, 512};
 
 inline int floor_div16(int v) { return v >> 4; }  // arithmetic shift: floors negatives too
 inline int wrap(int v, int n) {
@@ -216,7 +217,7 @@ class Planner {
     const TileShape& s = f.shape;
     int total = 0;
     const int npx = s.npx;
-    for (int g = 0; g < 8; g++) {  // 8 groups of 32 lanes
+    for (int g = 0; g < s.lanes / 32; g++) {  // groups of 32 lanes
       // a sample of the reads is enough to rank placements: first / last pixel of the lane, first / last stencil row
       for (int p = 0; p < npx; p += (npx > 1 ? npx - 1 : 1))
         for (int k = 0; k < opt_.ks; k += (opt_.ks > 1 ? opt_.ks - 1 : 1))
@@ -309,12 +310,12 @@ class Planner {
       }
     }
     // pixel words at a fixed stride, lane order of the gather; 16x16 tiles of a mixed plan use the first word of a uint4
-    const int wstride = tile_words(opt_.ks);
-    const int per_lane = wstride / 256;
+    const int wstride = tile_words(opt_.ks, opt_.waves);
+    const int per_lane = opt_.ks == 8 ? 1 : 4;
     const size_t wb = out->tlut.size();
     out->tlut.resize(wb + (size_t)wstride, kWordDead);
     uint32_t* w = &out->tlut[wb];
-    for (int tid = 0; tid < 256; tid++)
+    for (int tid = 0; tid < s.lanes; tid++)
       for (int p = 0; p < s.npx; p++) {
         int px, py;
         if (s.npx == 4) {
@@ -334,10 +335,26 @@ class Planner {
       }
     out->tiles.push_back(t);
     st.fetched_bytes += (int64_t)f.fetched * kStageChunk;
+    if (opt_.model_stats) {
+      // 128-byte lines the tile touches (what HBM delivers if no other workgroup's fetch of the line is still in L2)
+      int64_t lines = 0;
+      for (int r = 0; r < f.rows; r++) {
+        if (f.first[(size_t)r] < 0) continue;
+        const uint8_t* m = &f.mask[(size_t)r * f.ncols];
+        int prev = -(1 << 30);
+        for (int c = f.first[(size_t)r]; c <= f.last[(size_t)r]; c++)
+          if (m[c]) {
+            const int line = (f.c0 + c) >> 3;  // 8 chunks of 16 bytes
+            if (line != prev) lines++, prev = line;
+          }
+      }
+      st.line_bytes += lines * 128;
+    }
     st.lds_bytes += (int64_t)f.npos * kStageChunk;
     st.pieces_hist[f.pieces < 32 ? f.pieces : 32]++;
     if (opt_.model_stats && opt_.ks != 1) st.lds_cycles_model += lds_cycles(f);
-    (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq : st.n_16)++;
+    (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq
+     : s.kind == kTileWide128 ? st.n_wide128 : st.n_16)++;
   }
 
   // Execution order = raster order of the tiles (row by row, left to right): horizontally adjacent tiles -- whose
@@ -363,7 +380,7 @@ class Planner {
       }
       return x.oy != y.oy ? x.oy < y.oy : x.ox < y.ox;
     });
-    const size_t ws = (size_t)tile_words(opt_.ks), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+    const size_t ws = (size_t)tile_words(opt_.ks, opt_.waves), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
     std::vector<TileDesc> tiles(n);
     std::vector<uint32_t> tlut(out->tlut.size()), chunks(out->chunks.size());
     for (size_t i = 0; i < n; i++) {
@@ -396,6 +413,23 @@ class Planner {
         sq[k].empty = ox + 32 * k >= dw_ || oy >= dh_, sq[k].feasible = false;
       else
         footprint(ox + 32 * k, oy, kSquare, &sq[k]);
+    }
+    if (opt_.waves == 8 && wide_ok) {
+      // 128x16 tiles (workgroups of 8 waves): half the tile borders per pixel -- fewer halo bytes, and half as many row
+      // fragments that end inside a 128-byte line some other workgroup fetches again
+      Foot big[2];
+      footprint(ox, oy, kWide128, &big[0]);
+      footprint(ox, oy + 16, kWide128, &big[1]);
+      bool sq_ok = true;
+      int64_t cq = 0;
+      for (int k = 0; k < 4; k++) cq += cost_sq(k, &sq_ok);
+      const bool bf = !big[0].empty && big[0].feasible && (big[1].empty || big[1].feasible);
+      const int64_t cb = (big[0].empty ? 0 : big[0].fetched) + (big[1].empty ? 0 : big[1].fetched);
+      if (bf && (!sq_ok || cb * 100 <= cq * opt_.wide_pct)) {
+        emit(big[0], out, direct);
+        if (!big[1].empty) emit(big[1], out, direct);
+        return;
+      }
     }
     if (strip_ok) {
       bool ok = true, sq_ok = true;
@@ -482,8 +516,10 @@ class Planner {
       PlanStats& a = out->stats;
       const PlanStats& b = p.stats;
       a.n_strip += b.n_strip; a.n_wide += b.n_wide; a.n_sq += b.n_sq; a.n_16 += b.n_16; a.n_direct += b.n_direct;
+      a.n_wide128 += b.n_wide128;
       a.fetched_bytes += b.fetched_bytes; a.lds_bytes += b.lds_bytes; a.direct_pixels += b.direct_pixels;
       a.lds_cycles_model += b.lds_cycles_model;
+      a.line_bytes += b.line_bytes;
       for (int i = 0; i < 33; i++) a.pieces_hist[i] += b.pieces_hist[i];
     }
     if (opt_.order != 0) raster_order(out);

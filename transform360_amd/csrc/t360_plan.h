@@ -14,7 +14,8 @@ namespace t360 {
 
 struct PlanOptions {
   int ks = 4;            // taps per axis of the interpolation: 1, 2, 4, 8
-  int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces per copy (<= kMaxPieces)
+  int waves = 4;         // waves per workgroup of the gather kernel: 4, or 8 (then 128x16 tiles of 512 lanes exist)
+  int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces (<= kMaxPieces)
   int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
   int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
   int band = 4;          // order 0: region rows walked column by column (execution order, see t360_plan.cpp)
@@ -29,10 +30,11 @@ struct PlanOptions {
 };
 
 struct PlanStats {
-  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0;
+  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0, n_wide128 = 0;
   int64_t fetched_bytes = 0;   // distinct source chunks fetched per frame x 16 (HBM/L2 -> LDS, one copy)
   int64_t lds_bytes = 0;       // LDS positions per frame x 16 (incl. holes), one copy
   int64_t direct_pixels = 0;
+  int64_t line_bytes = 0;      // model_stats: bytes of the distinct 128-byte lines each tile touches, summed
   int64_t lds_cycles_model = 0;  // modelled ds_read_b64 LDS cycles (32-lane groups x stencil rows), summed over the tiles
   int pieces_hist[33] = {0};   // staged tiles per size (1 KiB pieces per copy)
 };

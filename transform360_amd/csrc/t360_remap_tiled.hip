@@ -73,10 +73,12 @@ struct Cls {
   static constexpr int K = kFit > kMaxSlots ? kMaxSlots : kFit;  // < 2: the class does not fit this ring
 };
 // smallest class that holds `pieces`
-#define T360_FOR_CLASS(pieces, F)   \
-  if ((pieces) <= 8) { F(8) }       \
+#define T360_FOR_CLASS(pieces, F)    \
+  if ((pieces) <= 8) { F(8) }        \
   else if ((pieces) <= 12) { F(12) } \
-  else { F(16) }
+  else if ((pieces) <= 16) { F(16) } \
+  else if ((pieces) <= 24) { F(24) } \
+  else { F(32) }
 
 // ---- per-pixel geometry -----------------------------------------------------------------------
 // KS = taps per axis: 1 nearest, 2 bilinear, 4 bicubic, 8 Lanczos4.  A stencil row is read as WIN 4-byte
@@ -103,25 +105,25 @@ struct PixelSetup {
 // What a workgroup fetches from its tile index alone, before (and in parallel with) the tile descriptor.
 struct TileFetch {
   uint32_t words[4];  // pixel words of this lane (16x16 tiles: words[0])
-  uint32_t chunk[4];  // chunk entries of this lane in pieces wave, wave + 4, wave + 8, wave + 12
+  uint32_t chunk[4];  // chunk entries of this lane in pieces wave, wave + WAVES, wave + 2 WAVES, wave + 3 WAVES
   uint32_t rowdw;     // dword `lane` of the row table = row_base of box rows 2*lane and 2*lane + 1
 };
 
-template <int KS>
+template <int KS, int WAVES>
 __device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, int max_pieces) {
   TileFetch f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (KS == 8) {
-    f.words[0] = pl.tlut[(size_t)tile * tile_words(KS) + tid];
+    f.words[0] = tid < 256 ? pl.tlut[(size_t)tile * tile_words(KS, WAVES) + tid] : kWordDead;
     f.words[1] = f.words[2] = f.words[3] = kWordDead;
   } else {
-    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)tile * tile_words(KS))[tid];
+    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)tile * tile_words(KS, WAVES))[tid];
     f.words[0] = v.x; f.words[1] = v.y; f.words[2] = v.z; f.words[3] = v.w;
   }
   const uint32_t* __restrict__ tc = pl.chunks + (size_t)tile * tile_chunk_dwords(max_pieces);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int piece = wave + 4 * j;
+    const int piece = wave + WAVES * j;
     f.chunk[j] = piece < max_pieces ? tc[piece * kPieceChunks + lane] : 0u;
   }
   f.rowdw = tc[max_pieces * kPieceChunks + lane];
@@ -381,7 +383,7 @@ __device__ __forceinline__ uint32_t out_pos(const TiledPlane& pl, const TileDesc
   const int tid = threadIdx.x;
   int ox, oy;
   if (NPX == 4) {
-    const int logw = t.kind == kTileStrip128 ? 7 : (t.kind == kTileWide64 ? 6 : 5);
+    const int logw = (t.kind == kTileStrip128 || t.kind == kTileWide128) ? 7 : (t.kind == kTileWide64 ? 6 : 5);
     const int x = tid & ((1 << logw) - 1), band = tid >> logw;
     if (dword_store) {
       ox = t.ox + (x & ~3);
@@ -431,16 +433,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // A wave's share of one copy of one frame of one tile, global -> LDS by DMA: nj x (64 lanes x 16 bytes), nj
-// wave-uniform in 1..4; the wave's pieces are 4 KiB apart in LDS (wave w moves pieces w, w+4, w+8, ...).
+// wave-uniform in 1..4; the wave's pieces are lds_step bytes apart in LDS (wave w of W moves pieces w, w+W, w+2W, ...).
 // SGPR-base + 32-bit VGPR-offset addressing, so per frame only the scalar base changes; M0 (the LDS destination)
 // is written and stepped next to the instruction that uses it.  hipcc does not count these loads
 // (cdna_hip_programming.md 5.7): completion is ours to track with wait_vmcnt().
 // The 4 {load; step M0 by an SGPR; nop} triples are 16 bytes each (8 + 4 + 4) and laid out back to back; a computed
 // jump enters the chain at triple 4-nj (Duff's device), so no per-frame decision tree.  Triple k moves the
 // wave's piece 3-k: `off[k]` must hold its source offset; M0 starts at the last piece's destination and walks down.
-__device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, uint32_t lds_dst, const int (&off)[4]) {
+__device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, uint32_t lds_dst, uint32_t lds_step,
+                                            const int (&off)[4]) {
   const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(4 - nj)));
-  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * 4096u));
+  const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * lds_step));
 #define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %4\n\ts_sub_u32 m0, m0, %7\n\ts_nop 0\n\t"
   asm volatile(
       "s_mov_b32 m0, %5\n\t"
@@ -450,7 +453,7 @@ __device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, u
       "s_setpc_b64 vcc\n\t"
       T360_DMA(0) T360_DMA(1) T360_DMA(2) T360_DMA(3)
       :
-      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(frame_base), "s"(m0_start), "s"(skip), "s"(4096u)
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(frame_base), "s"(m0_start), "s"(skip), "s"(lds_step)
       : "memory", "vcc", "scc");
 #undef T360_DMA
 }
@@ -483,7 +486,7 @@ __device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
 // stores, has no store younger than the loads it is about to wait for: loads complete in order among themselves, so
 // "at most D operations outstanding", D = my loads younger than frame i's, implies frame i's pieces are done whatever
 // the (older) stores do.
-template <int NPX, int KS, int GROUP, int P, int K>
+template <int NPX, int KS, int GROUP, int P, int K, int WAVES>
 __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, const TileFetch& tf,
                                            const uint8_t* __restrict__ lds, int f0, int f1) {
   constexpr bool DUAL = dual_copy(KS);
@@ -491,7 +494,9 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   (void)lane;
-  const int mine = ((int)t.pieces - wave + 3) >> 2;  // my pieces: wave, wave + 4, wave + 8, wave + 12 (0..4 of them)
+  const int mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;  // my pieces: wave, wave + WAVES, ... (0..4 of them)
+  // does this wave hold pixels?  (a 256-lane tile in a workgroup of 8 waves: waves 4..7 only move bytes)
+  const bool has_px = WAVES == 4 || t.kind == kTileWide128 || wave < 4;
   // chunk q = lane + 64*piece lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
   // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
   int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4's order)
@@ -499,14 +504,14 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   for (int k = 0; k < 4; k++) {
     const int j = 3 - k;
     const uint32_t e = tf.chunk[j];
-    goff[k] = (j < mine && 4 * j < P) ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
+    goff[k] = (j < mine && WAVES * j < P) ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds + (uint32_t)wave * 1024u;
   auto issue = [&](int f, int slot_bytes) {
     if (mine <= 0) return;
     const uint8_t* base = T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)f * pl.src_frame_bytes));
-    dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, goff);
-    if (DUAL && !T360_DBG(a, 5)) dma_frame_4(mine, base, lds_base + (uint32_t)(slot_bytes + R::kCopyB), goff);
+    dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, WAVES * 1024u, goff);
+    if (DUAL && !T360_DBG(a, 5)) dma_frame_4(mine, base, lds_base + (uint32_t)(slot_bytes + R::kCopyB), WAVES * 1024u, goff);
   };
   const int per_frame = DUAL ? 2 * mine : mine;  // my DMA instructions per frame
   const int nf = f1 - f0;
@@ -529,18 +534,18 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
       wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
       frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
       if (i + S > 0) {                                                                                     \
-        emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                                      \
+        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                          \
         d += pl.dst_frame_bytes;                                                                           \
       }                                                                                                    \
       if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
-      if (!T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store);           \
+      if (has_px && !T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store); \
       if (i + S == 0) T360_MARK(a, 3);                                                                     \
       if (i + S == 1) T360_MARK(a, 4);                                                                     \
     }
     T360_STEP(0) T360_STEP(1) T360_STEP(2) T360_STEP(3)
 #undef T360_STEP
   }
-  if (nf > 0) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
+  if (nf > 0 && has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
   T360_MARK(a, 5);
 }
 
@@ -550,6 +555,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
 template <int KS>
 __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, int f0, int f1) {
   const int tid = threadIdx.x;
+  if (tid >= 256) return;  // 16x16 pixels
   const int ox = t.ox + (tid & 15), oy = t.oy + (tid >> 4);
   if (ox >= pl.dw || oy >= pl.dh) return;
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
@@ -619,8 +625,8 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
 }
 
 // Grid (1-D): the direct tiles' work items first (they are the slowest per pixel), then the staged tiles'.
-template <int KS, int RINGKB>
-__global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
+template <int KS, int RINGKB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void remap_tiled_kernel(TiledArgs a) {
 #ifndef T360_GROUP
 #define T360_GROUP 4
 #endif
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
   // Work items = (tile, frame group), numbered with the frame group fastest: the groups of one tile start within
   // microseconds of each other on the same XCD, so the tile's tables come from HBM once and from L2 afterwards.
-  int id = blockIdx.x, b, g;
+  int id = blockIdx.x, b, g, f0, f1;
   // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
   // hipcc copy the whole argument block to scratch
   TiledPlane pl = a.plane[0];
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
     const int count = pole ? pl.ndirect - pl.ndirect_top : pl.ndirect_top;
     if (t_local >= count) return;
     b = pole ? pl.ndirect_top + t_local : t_local;
-    const int f0 = g * a.frames_per_block;
+    f0 = g * a.frames_per_block;
     direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + b], f0, min(f0 + a.frames_per_block, a.nframes));
     return;
   }
@@ -659,13 +665,27 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
     const int xcd = id & 7, k = id >> 3;
     const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
     const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
-    const int t_local = k / a.groups;
-    if (t_local >= len) return;
-    b = start + t_local;
-    g = k - t_local * a.groups;
+    // The last tiles of every XCD's range walk the batch in shorter runs (tail_frames instead of frames_per_block):
+    // the workgroups that finish the launch are then short ones, and the machine drains in ~tail_frames frame times
+    // instead of frames_per_block (a quarter of the grid costs a few extra start-ups, the tail shrinks 4x).
+    const int len_tail = (len * a.tail_percent) / 100, len_head = len - len_tail;
+    int fpb;
+    if (k < len_head * a.groups) {
+      const int t_local = k / a.groups;
+      b = start + t_local;
+      g = k - t_local * a.groups;
+      fpb = a.frames_per_block;
+    } else {
+      const int k2 = k - len_head * a.groups;
+      const int t_local = k2 / a.tail_groups;
+      if (t_local >= len_tail) return;
+      b = start + len_head + t_local;
+      g = k2 - t_local * a.tail_groups;
+      fpb = a.tail_frames;
+    }
+    f0 = g * fpb;
+    f1 = min(f0 + fpb, a.nframes);
   }
-  const int f0 = g * a.frames_per_block;
-  const int f1 = min(f0 + a.frames_per_block, a.nframes);
   if (a.nplanes > 1 && b >= pl.ntiles) {
     b -= pl.ntiles;
     pl = a.plane[1];
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
       }
     }
   }
-  const TileFetch tf = fetch_tile<KS>(pl, b, a.max_pieces);  // independent of the descriptor: all in flight together
+  const TileFetch tf = fetch_tile<KS, WAVES>(pl, b, a.max_pieces);  // independent of the descriptor: all in flight together
   const TileDesc t = pl.tiles[b];
 #ifdef T360_INSTRUMENT
   if (a.trace && threadIdx.x == 0) {
@@ -696,13 +716,13 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
   const int pieces = (int)t.pieces;
   if (KS == 8 || t.kind == kTileStaged16) {
 #define T360_TILE1(P) \
-    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K>(a, pl, t, tf, lds, f0, f1);
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
     T360_FOR_CLASS(pieces, T360_TILE1)
 #undef T360_TILE1
   } else {
 #define T360_TILE4(P)                                                        \
     if constexpr (Cls<RINGKB, P, DUAL>::K >= 2)                               \
-      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K>(a, pl, t, tf, lds, f0, f1);
+      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
     T360_FOR_CLASS(pieces, T360_TILE4)
 #undef T360_TILE4
   }
@@ -711,38 +731,56 @@ __global__ __launch_bounds__(256) void remap_tiled_kernel(TiledArgs a) {
 // largest tile (in pieces) the ring of RINGKB KiB can hold two frames of
 template <int RINGKB, bool DUAL>
 constexpr int max_pieces_of() {
-  return Cls<RINGKB, 16, DUAL>::K >= 2 ? 16 : Cls<RINGKB, 12, DUAL>::K >= 2 ? 12 : Cls<RINGKB, 8, DUAL>::K >= 2 ? 8 : 0;
+  return Cls<RINGKB, 32, DUAL>::K >= 2   ? 32
+         : Cls<RINGKB, 24, DUAL>::K >= 2 ? 24
+         : Cls<RINGKB, 16, DUAL>::K >= 2 ? 16
+         : Cls<RINGKB, 12, DUAL>::K >= 2 ? 12
+         : Cls<RINGKB, 8, DUAL>::K >= 2  ? 8
+                                         : 0;
 }
 
-template <int KS, int RINGKB>
+template <int KS, int RINGKB, int WAVES>
 hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
   constexpr int lds_bytes = RINGKB * 1024;
   if (a.max_pieces > max_pieces_of<RINGKB, dual_copy(KS)>()) return hipErrorInvalidValue;
   if (lds_bytes > 64 * 1024) {
     // per device and cheap: not cached (handles may live on several devices of one process)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, RINGKB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, RINGKB, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
   }
   const int per_xcd = (a.total_tiles + 7) / 8;
-  hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB>), dim3(a.direct_blocks + 8 * per_xcd * groups, 1, 1), dim3(256),
+  const int tail = (per_xcd * a.tail_percent) / 100;
+  const int items = (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;  // >= any XCD's item count
+  hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB, WAVES>), dim3(a.direct_blocks + 8 * items, 1, 1), dim3(64 * WAVES),
                      (size_t)lds_bytes, stream, a);
   return hipGetLastError();
 }
 
 template <int KS>
 hipError_t launch_ks(const TiledArgs& a, int groups, hipStream_t stream) {
-  if (a.ring_kb == 26) return launch_one<KS, 26>(a, groups, stream);  // 6 workgroups per CU
-  if (a.ring_kb == 31) return launch_one<KS, 31>(a, groups, stream);  // 5 workgroups per CU
-  if (a.ring_kb == 38) return launch_one<KS, 38>(a, groups, stream);  // 4 workgroups per CU
+  if (a.waves == 8) {
+    if (a.ring_kb == 76) return launch_one<KS, 76, 8>(a, groups, stream);  // 2 workgroups of 8 waves per CU
+#ifdef T360_INSTRUMENT
+    if (a.ring_kb == 50) return launch_one<KS, 50, 8>(a, groups, stream);  // 3 workgroups of 8 waves per CU
+#endif
+    return hipErrorInvalidValue;
+  }
+  if (a.ring_kb == 38) return launch_one<KS, 38, 4>(a, groups, stream);  // 4 workgroups of 4 waves per CU
+#ifdef T360_INSTRUMENT
+  if (a.ring_kb == 26) return launch_one<KS, 26, 4>(a, groups, stream);  // 6 workgroups per CU
+  if (a.ring_kb == 31) return launch_one<KS, 31, 4>(a, groups, stream);  // 5 workgroups per CU
+  if (a.ring_kb == 50) return launch_one<KS, 50, 4>(a, groups, stream);  // 3 workgroups per CU
+  if (a.ring_kb == 76) return launch_one<KS, 76, 4>(a, groups, stream);  // 2 workgroups per CU
+#endif
   return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-const char* remap_tiled_kernel_name(int ks, int ring_kb) {
+const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves) {
   static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d>", ks, ring_kb);
+  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d, %d>", ks, ring_kb, waves);
   return buf;
 }
 

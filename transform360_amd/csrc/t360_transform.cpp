@@ -186,11 +186,14 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
 #ifdef T360_INSTRUMENT
   // tuning switches of the instrumented build (tools/ab.sh); the shipped library reads no environment
   if (const char* e = getenv("T360_RING_KB")) ring_kb_ = atoi(e);
+  if (const char* e = getenv("T360_WAVES")) waves_ = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("T360_MAX_PIECES")) max_pieces_ = atoi(e);
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4096) frames_per_block_ = v;
   }
+  if (const char* e = getenv("T360_TAIL_PCT")) tail_percent_ = atoi(e);
+  if (const char* e = getenv("T360_TAIL_FRAMES")) tail_frames_ = atoi(e);
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
@@ -870,9 +873,19 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     for (int k = 0; k < njobs; k++) printf("Could not find interpolation algorithm for plane %d", jobs[k].image_plane);
     return true;
   }
-  for (int k = 0; k < njobs; k++) {
-    const PlaneState& p = planes_[jobs[k].idx];
-    if (jobs[k].out_h != p.map_h || jobs[k].out_w != p.map_w) return runPlanesScaled(jobs, njobs, n_frames);  // :735-737
+  {
+    // planes whose output size differs from their warp map take the resize branch (:735-737, :759-776); a batch may
+    // mix both kinds (rounding: a factor of 1.0006 scales 1000 -> 1001 but 500 -> 500), so split it
+    std::vector<PlaneJob> scaled, plain;
+    for (int k = 0; k < njobs; k++) {
+      const PlaneState& p = planes_[jobs[k].idx];
+      (jobs[k].out_h != p.map_h || jobs[k].out_w != p.map_w ? scaled : plain).push_back(jobs[k]);
+    }
+    if (!scaled.empty()) {
+      if (!runPlanesScaled(scaled.data(), (int)scaled.size(), n_frames)) return false;
+      if (plain.empty()) return true;
+      return runPlanes(plain.data(), (int)plain.size(), n_frames);
+    }
   }
 
   // ---- stage 1: segmented low-pass into the scratch planes (filterPlane, :621-704) ----
@@ -928,8 +941,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.nframes = n_frames;
     fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
     fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
-    fused.max_pieces = max_pieces_;
-    fused.ring_kb = ring_kb_;
+    // Lanczos4 plans hold 16x16 tiles only (one pixel per lane, 32 weight dwords each): workgroups of 4 waves
+    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : max_pieces_;
+    fused.ring_kb = fused.ks == 8 && waves_ == 8 ? 38 : ring_kb_;
+    fused.waves = fused.ks == 8 ? 4 : waves_;
 #ifdef T360_INSTRUMENT
     fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
 #endif
@@ -937,6 +952,9 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   auto flush_fused = [&]() -> bool {
     if (fused.nplanes == 0) return true;
     fused.groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+    fused.tail_frames = std::max(1, std::min(fused.frames_per_block, tail_frames_));
+    fused.tail_groups = (n_frames + fused.tail_frames - 1) / fused.tail_frames;
+    fused.tail_percent = fused.tail_groups > fused.groups ? tail_percent_ : 0;
     int max_pole = 0;
     for (int k = 0; k < fused.nplanes; k++)
       max_pole = std::max(max_pole, std::max(fused.plane[k].ndirect_top, fused.plane[k].ndirect - fused.plane[k].ndirect_top));
@@ -944,7 +962,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
 #ifdef T360_INSTRUMENT
     t360::DeviceBuffer trace;
     const char* trace_path = getenv("T360_TRACE");
-    const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * ((fused.total_tiles + 7) / 8) * fused.groups;
+    const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * (((fused.total_tiles + 7) / 8) + 1) * std::max(fused.groups, fused.tail_groups);
     if (trace_path && trace.reserve(nwg * 64) && hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
       fused.trace = trace.as<unsigned long long>();
 #endif
@@ -961,7 +979,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       }
     }
 #endif
-    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.ring_kb);
+    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.ring_kb, fused.waves);
     reset_fused();
     return ok;
   };
@@ -1043,7 +1061,8 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
     return false;
   PlanOptions o;
   o.ks = ks;
-  o.max_pieces = max_pieces_;
+  o.waves = ks == 8 ? 4 : waves_;
+  o.max_pieces = ks == 8 ? std::min(max_pieces_, 16) : max_pieces_;
   o.wide_pct = plan_wide_pct_;
   o.strip_pct = plan_strip_pct_;
   o.band = plan_band_ > 0 ? plan_band_ : 4;

@@ -131,12 +131,16 @@ class VideoFrameTransform {
   t360::DeviceBuffer weights_;  // Q15 table of ctx_.interpolation_alg
   t360::DeviceBuffer weights_pack_;  // bicubic weights re-packed for v_dot4 (tiled kernel)
   bool weights_ready_ = false;
-  // LDS-tiled gather: staging budget per tile and copy (1 KiB pieces) and LDS ring per workgroup (38 KiB: 4
-  // workgroups per CU; a tile of up to 4 / 6 / 8 pieces keeps 4 / 3 / 2 frames in flight)
-  int max_pieces_ = 16;
-  int ring_kb_ = 38;
+  // LDS-tiled gather: workgroups of 8 waves (128x16 px tiles: half the tile borders of 64x16 -- fewer halo bytes and
+  // fewer row fragments ending inside 128-byte lines another workgroup fetches again), 76 KiB of LDS each (2 per CU:
+  // 16 waves, the same as 4 x 4, but half as many tiles' working sets contend for the XCD's L2), up to 24 KiB staged
+  // per tile and frame; the ring keeps 3 frames of small tiles, 2 of the largest
+  int max_pieces_ = 24;
+  int ring_kb_ = 76;
+  int waves_ = 8;
   int frames_per_block_ = 64;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
+  int tail_percent_ = 25, tail_frames_ = 16;  // the last quarter of the tile list walks the batch in runs of 16 frames
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
