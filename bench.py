@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison (development sweeps only)")
+    ap.add_argument("--no-host-abi", action="store_true", help="skip the host-pointer ABI leg (profiling runs)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -422,7 +423,7 @@ def main():
             except RuntimeError:
                 pass
         res["Mpix_s_in"] = round(fps * in_w * in_h / 1e6, 1)
-        if world == 1 and args.config == 2 and not os.environ.get("T360_TRACE"):  # (a trace run keeps its last launch)
+        if world == 1 and args.config == 2 and not args.no_host_abi and not os.environ.get("T360_TRACE"):
             res["host_abi"] = host_abi_rate(wl, lin, lout, ctx)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)

@@ -23,15 +23,17 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(pmc, "*", "*counter_collection.csv")):
     with open(path) as f:
         for row in csv.DictReader(f):
-            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-name = max((k for k in acc if "remap_tiled" in k or "remap_gather_kernel" in k),
-           key=lambda k: sum(acc[k].get("TCC_EA0_RDREQ_sum", [0])), default=None)
+            # one key per (kernel, grid): the same kernel also runs small single-plane launches (host-pointer ABI leg)
+            acc[(row["Kernel_Name"], row.get("Grid_Size", ""))][row["Counter_Name"]].append(float(row["Counter_Value"]))
+name = max((k for k in acc if "remap_tiled" in k[0] or "remap_gather_kernel" in k[0]),
+           key=lambda k: (lambda v: sum(v) / max(1, len(v)))(acc[k].get("TCC_EA0_RDREQ_sum", [0])), default=None)
 if name is None:
     sys.exit("no gather kernel found in %s" % pmc)
 m = {k: sum(v) / len(v) for k, v in acc[name].items()}
 rd = 32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * m.get("TCC_EA0_RDREQ_128B_sum", 0)
 wr = 64 * m.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (m.get("TCC_EA0_WRREQ_sum", 0) - m.get("TCC_EA0_WRREQ_64B_sum", 0))
-res = {"config": config, "frames": frames, "kernel": (re.search(r"(\w+_kernel)", name).group(1) if re.search(r"(\w+_kernel)", name) else name),
+res = {"config": config, "frames": frames, "grid": name[1],
+       "kernel": (re.search(r"(\w+_kernel)", name[0]).group(1) if re.search(r"(\w+_kernel)", name[0]) else name[0]),
        "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
        "hbm_bytes_per_launch": int(rd + wr),
        "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
   rm -rf /tmp/pl && mkdir -p /tmp/pl
   env $cfg timeout 60 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
-      --output-format csv -d /tmp/pl/mem1 -o mem1 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA:-} > /tmp/pl/log 2>&1
+      --output-format csv -d /tmp/pl/mem1 -o mem1 -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-verify ${BENCH_EXTRA:-} > /tmp/pl/log 2>&1
   echo "== $cfg"
   python "$R/tools/pmc_summary.py" /tmp/pl 2>/dev/null | awk "/kernel=.*remap_tiled/,/^kernel=zzz/" | grep -E "kernel=|TCC_" | head -8
 done

@@ -1,23 +1,29 @@
 #!/bin/bash
 # tools/profile_round.sh <tag> : the profile set committed under profiles/ for one round.
-#   1. rocprofv3 --kernel-trace --stats of the default bench.py run  -> profiles/<tag>_kernel_stats.csv
-#   2. PMC passes (SQ, TCC memory-side) of the same command           -> profiles/<tag>_pmc_summary.txt
-#   3. HBM bytes per launch from the PMC passes                       -> profiles/traffic_latest.json
-# Run on the GPU box:  gpurun -- 'tools/profile_round.sh r01'
+#   1. rocprofv3 --kernel-trace --stats of the default bench.py run (config 2)  -> profiles/<tag>_kernel_stats.csv
+#      and of configs 1, 3, 4                                                    -> profiles/<tag>_cfgN_kernel_stats.csv
+#   2. PMC passes (SQ, TCC memory-side; separate runs, --kernel-trace only)      -> profiles/<tag>_pmc_summary.txt
+#   3. HBM bytes per launch from the PMC passes                                  -> profiles/<tag>_traffic.json
+#   4. the plain bench.py line of the same build                                 -> profiles/<tag>_bench_default.json
+# Run on the GPU box:  gpurun -- 'tools/profile_round.sh r02'
 set -u
 TAG=$1
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$R/profiles"
-FRAMES=${FRAMES:-64}
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- \
-    python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --frames $FRAMES > "$OUT/trace.log" 2>&1
-cp "$OUT/trace/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_kernel_stats.csv" 2>/dev/null
-grep -h "^{\"metric\"" "$OUT/trace.log" | tail -1 > "$R/profiles/${TAG}_bench_under_rocprof.json"
-cd "$R" && PMC_MEM=1 tools/prof_pmc.sh "$OUT/pmc" --frames $FRAMES > /dev/null 2>&1
+python "$R/bench.py" > "$OUT/bench_default.log" 2>&1
+grep -h "^{\"metric\"" "$OUT/bench_default.log" | tail -1 > "$R/profiles/${TAG}_bench_default.json"
+for CFG in 2 1 3 4; do
+  SUF=$([ $CFG = 2 ] && echo "" || echo "_cfg$CFG")
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$CFG" -o "$TAG" -- \
+      python "$R/bench.py" --config $CFG --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/trace$CFG.log" 2>&1
+  cp "$OUT/trace$CFG/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}${SUF}_kernel_stats.csv" 2>/dev/null
+  grep -h "^{\"metric\"" "$OUT/trace$CFG.log" | tail -1 > "$R/profiles/${TAG}${SUF}_bench_under_rocprof.json"
+done
+cd "$R" && PMC_MEM=1 tools/prof_pmc.sh "$OUT/pmc" --no-verify > /dev/null 2>&1
 cp "$OUT/pmc/summary.txt" "$R/profiles/${TAG}_pmc_summary.txt"
-python tools/make_traffic.py "$OUT/pmc" 2 $FRAMES "$R/profiles/traffic_latest.json"
-cp "$R/profiles/"* "$R/gpurun_out/" 2>/dev/null
-mkdir -p "$R/gpurun_out/profiles" && cp "$R/profiles/"* "$R/gpurun_out/profiles/"
-head -5 "$R/profiles/${TAG}_kernel_stats.csv"
+python tools/make_traffic.py "$OUT/pmc" 2 64 "$R/profiles/${TAG}_traffic.json"
+mkdir -p "$R/gpurun_out/profiles" && cp "$R/profiles/${TAG}"* "$R/gpurun_out/profiles/"
+head -4 "$R/profiles/${TAG}_kernel_stats.csv" | cut -c1-200
+cat "$R/profiles/${TAG}_traffic.json"

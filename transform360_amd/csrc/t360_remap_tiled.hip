@@ -284,6 +284,34 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
     // nearest: the byte itself (cv::remap INTER_NEAREST)
 #pragma unroll
     for (int p = 0; p < NPX; p++) v[p] = lds[s.addr[p][0] + SLOT];
+  } else if (KS == 8) {
+    // Lanczos4: 8 rows x 8 taps.  The rows go through in two halves (12 LDS dwords in flight each) and every window
+    // is consumed as soon as it is assembled: the 64 weights already take 32 registers per pixel.
+    static_assert(KS != 8 || NPX == 1, "Lanczos4 tiles hold one pixel per lane");
+    const uint32_t sh = s.sh[0];
+    int hi = s.hb[0];
+    uint32_t lo = 1u << (kCoefBits - 1);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t d[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[r][k] = *reinterpret_cast<const uint32_t*>(lds + s.addr[0][4 * h + r] + SLOT + 4 * k);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) asm volatile("" : "+v"(d[r][k]));
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          const uint32_t px4 = __builtin_amdgcn_alignbit(d[r][w + 1], d[r][w], sh);
+          hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[0][(4 * h + r) * 2 + w], hi, false);
+          lo = __builtin_amdgcn_udot4(px4, s.wl[0][(4 * h + r) * 2 + w], lo, false);
+        }
+    }
+    v[0] = sat_u8(((hi << 8) + (int)lo) >> kCoefBits);
   } else {
     int t15[NPX];
 #pragma unroll
@@ -626,7 +654,7 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
 
 // Grid (1-D): the direct tiles' work items first (they are the slowest per pixel), then the staged tiles'.
 template <int KS, int RINGKB, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void remap_tiled_kernel(TiledArgs a) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void remap_tiled_kernel(TiledArgs a) {
 #ifndef T360_GROUP
 #define T360_GROUP 4
 #endif
