@@ -16,6 +16,13 @@
  *   - "...WidthWithPadding" is the row stride in BYTES (AVFrame.linesize).
  *   - frame buffers are borrowed for the duration of the call only.
  *
+ * Attribution: the declarations below (function names and signatures / enumerator names and values,
+ * the field names, order and types of FrameTransformContext) reproduce the public interface of
+ * facebook/transform360, Copyright (c) 2015-present, Facebook, Inc., released under the BSD license
+ * in that project's LICENSE file.  They are repeated here only because binary compatibility with
+ * that interface is the purpose of this library; everything behind them is an independent
+ * implementation.
+ *
  * What is different behind the boundary: maps, low-pass filtering and the gather
  * run as HIP kernels on an MI355X.  inputData / outputData may be host pointers
  * (staged over PCIe, synchronous like the reference) or device pointers (used in

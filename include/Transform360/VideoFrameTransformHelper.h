@@ -14,6 +14,13 @@
  *     - FrameTransformContext (:56-90) 28 four-byte fields, 112 bytes, copied by value
  *       at VideoFrameTransform_new (reference VideoFrameTransform.cpp:206-208)
  *
+ * Attribution: the declarations below (function names and signatures / enumerator names and values,
+ * the field names, order and types of FrameTransformContext) reproduce the public interface of
+ * facebook/transform360, Copyright (c) 2015-present, Facebook, Inc., released under the BSD license
+ * in that project's LICENSE file.  They are repeated here only because binary compatibility with
+ * that interface is the purpose of this library; everything behind them is an independent
+ * implementation.
+ *
  * Nothing here depends on HIP, OpenCV or C++.
  */
 #ifndef TRANSFORM360_VIDEOFRAMETRANSFORMHELPER_H
