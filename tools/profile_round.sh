@@ -17,7 +17,7 @@ grep -h "^{\"metric\"" "$OUT/bench_default.log" | tail -1 > "$R/profiles/${TAG}_
 for CFG in 2 1 3 4; do
   SUF=$([ $CFG = 2 ] && echo "" || echo "_cfg$CFG")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$CFG" -o "$TAG" -- \
-      python "$R/bench.py" --config $CFG --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/trace$CFG.log" 2>&1
+      python "$R/bench.py" --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-host-abi > "$OUT/trace$CFG.log" 2>&1
   cp "$OUT/trace$CFG/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}${SUF}_kernel_stats.csv" 2>/dev/null
   grep -h "^{\"metric\"" "$OUT/trace$CFG.log" | tail -1 > "$R/profiles/${TAG}${SUF}_bench_under_rocprof.json"
 done
