@@ -21,7 +21,7 @@ def main():
         for k in keys:
             os.environ.pop(k, None)
         os.environ.update(v)
-        ov = dict(num_vertical_segments=5, num_horizontal_segments=4) if "T360_NO_FAST_LOWPASS" in v else dict(
+        ov = dict(num_vertical_segments=5, num_horizontal_segments=4) if ("T360_NO_FAST_LOWPASS" in v or "T360_NO_WIDE_LOWPASS" in v) else dict(
             enable_low_pass_filter=0)
         _batch_case(handler, O, ov, n=5, extra_pad=0)
         print("ok", v, flush=True)

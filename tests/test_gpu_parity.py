@@ -245,6 +245,7 @@ VARIANTS = [
     {"T360_ROW_ALIGN": "1"}, {"T360_ROW_ALIGN": "4"}, {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"},
     {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
     {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+    {"T360_NO_WIDE_LOWPASS": "1"},
 ]
 
 

@@ -68,7 +68,12 @@ struct SegmentDev {
   int ky_off, ky_len;
   int fixed_point;     // 1: Q8 x Q8 integer path, 0: float path
   int kxp_off, kx_groups;  // packed byte taps of the fast low-pass path (kx_groups = 0: not eligible)
+  int kxs_off, kxs_nd;     // shifted byte taps of the wide fast path: 4 variants x kWideTapStride dwords, of which
+                           // the first kxs_nd are non-zero (kxs_nd = 0: not eligible); t360_lowpass.hip
 };
+constexpr int kWideTapStride = 12;  // dwords per shifted tap variant (zero padded)
+constexpr int kWideMaxNd = 11;      // longest window, in dwords, the wide low-pass path instantiates
+constexpr int kWideTileW = 512, kWideTileH = 32;
 
 // One unit of low-pass work: a tile of one segment (tiles never straddle segments because the
 // filter kernels change at segment borders).

@@ -99,6 +99,14 @@ struct LowpassArgs {
   int fast_lds_bytes;         // max over fast tiles of the staged source rectangle
   const uint32_t* taps_pk;    // horizontal Q8 taps packed 4 per dword, zero padded (SegmentDev::kxp_off)
   int dst_dword_ok;           // dst base and stride are multiples of 4
+  // wide fast path (lowpass_q8w_kernel): tiles of <= 512 x 32 px of a run of segments with identical kernels,
+  // x0 a multiple of 4; listed row-major, executed in XCD-contiguous ranges
+  const LowpassTile* wide_tiles;
+  int nwide;
+  int wide_lds_bytes;
+  const uint32_t* taps_sh;    // SegmentDev::kxs_off
+  int wide_frames;            // frames one workgroup of the wide path walks with its tile
+  int nframes;                // (set by launch_lowpass)
 };
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
 

@@ -201,6 +201,8 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_ROW_ALIGN")) plan_row_align_ = atoi(e);
   if (getenv("T360_NO_TILED")) use_tiled_ = false;
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
+  if (getenv("T360_NO_WIDE_LOWPASS")) use_wide_lowpass_ = false;
+  if (const char* e = getenv("T360_LOWPASS_FRAMES")) lowpass_frames_ = std::max(1, atoi(e));
 #endif
   ok_ = true;
 }
@@ -467,7 +469,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     std::vector<SegmentDev> segs;
     std::vector<int> q8;
     std::vector<float> f32;
-    std::vector<uint32_t> pk;
+    std::vector<uint32_t> pk, sh;
     p.seg_fast.clear();
     p.fast_ky = 0;
     for (const Segment& s : p.filter.segments) {
@@ -491,7 +493,28 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
           pk.push_back(w);
         }
       }
-      p.seg_fast.push_back(fast ? 1 : 0);
+      // wide fast path: the row pass of output pixel px0 + j (px0 % 4 == 0, j = 0..3) is a dot product of the
+      // ALIGNED source dwords from (px0 - rx - m) on, m = (-rx) & 3, with the taps shifted by m + j bytes -- four
+      // variants of the packed taps instead of a realignment of the pixels per output pixel
+      d.kxs_off = (int)sh.size();
+      d.kxs_nd = 0;
+      if (fast) {
+        const int kx = (int)s.kx_q8.size(), rx = kx / 2, m = (4 - rx % 4) % 4;
+        const int nd = (kx + m + 3 + 3) / 4;
+        if (nd <= kWideMaxNd) {
+          d.kxs_nd = nd;
+          for (int j = 0; j < 4; j++)
+            for (int i = 0; i < kWideTapStride; i++) {
+              uint32_t w = 0;
+              for (int b = 0; b < 4; b++) {
+                const int k = 4 * i + b - (m + j);
+                if (k >= 0 && k < kx) w |= (uint32_t)s.kx_q8[(size_t)k] << (8 * b);
+              }
+              sh.push_back(w);
+            }
+        }
+      }
+      p.seg_fast.push_back(fast ? (d.kxs_nd ? 2 : 1) : 0);
       d.left = s.left;
       d.top = s.top;
       d.width = s.width;
@@ -509,6 +532,11 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     }
     if (!segs.empty()) {
       if (pk.empty()) pk.push_back(0);
+      if (sh.empty()) sh.push_back(0);
+      if (!p.taps_sh.reserve(sh.size() * sizeof(uint32_t))) return check(hipErrorOutOfMemory, "hipMalloc(segments)");
+      if (!check(hipMemcpyAsync(p.taps_sh.as<void>(), sh.data(), sh.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                stream_), "hipMemcpy(taps)"))
+        return false;
       if (!p.segs.reserve(segs.size() * sizeof(SegmentDev)) || !p.taps_q8.reserve(q8.size() * sizeof(int)) ||
           !p.taps_f32.reserve(f32.size() * sizeof(float)) || !p.taps_pk.reserve(pk.size() * sizeof(uint32_t)))
         return check(hipErrorOutOfMemory, "hipMalloc(segments)");
@@ -638,8 +666,8 @@ static bool same_run(const t360::Segment& a, const t360::Segment& b) {
 // VideoFrameTransform.cpp:630-691: every segment once per eye).
 bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex) {
   if (p.tiles_w == w && p.tiles_h == h) return true;
-  std::vector<LowpassTile> tiles, fast_tiles, rest_tiles;
-  int max_rows_rest = 0, fast_lds = 0;
+  std::vector<LowpassTile> tiles, fast_tiles, rest_tiles, wide_tiles;
+  int max_rows_rest = 0, fast_lds = 0, wide_lds = 0;
   int ox[2] = {0, 0}, oy[2] = {0, 0}, eyes = 1;
   if (ctx_.input_stereo_format == STEREO_FORMAT_LR) {
     eyes = 2;
@@ -697,6 +725,23 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
             run_w += p.filter.segments[k].width;
           bool inside = L + run_w <= w;  // every member was range-checked above only one at a time
           if (!inside) run_w = s.width;
+          if (p.seg_fast[i] == 2 && L % 4 == 0 && w % 16 == 0 && use_wide_lowpass_) {
+            // wide tiles, row-major: <= 512 x 32 px (2 row groups of 128 lanes x 4 px)
+            const int nd = ((int)s.kx_q8.size() + (4 - ((int)s.kx_q8.size() / 2) % 4) % 4 + 6) / 4;
+            for (int y = 0; y < s.height; y += kWideTileH)
+              for (int x = 0; x < run_w; x += kWideTileW) {
+                LowpassTile t;
+                t.seg = (int)i;
+                t.x0 = L + x;
+                t.y0 = T + y;
+                t.w = std::min(kWideTileW, run_w - x);
+                t.h = std::min(kWideTileH, s.height - y);
+                wide_tiles.push_back(t);
+                const int ndw = 3 + (t.w + 3) / 4 + nd - 1;  // the staged rectangle starts 16-byte aligned: <= 3 dwords early
+                wide_lds = std::max(wide_lds, (t.h + 2 * ry) * ((ndw + 3) & ~3) * 4);
+              }
+            continue;
+          }
           for (int y = 0; y < s.height; y += 128)
             for (int x = 0; x < run_w; x += 128) {
               LowpassTile t;
@@ -727,6 +772,14 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
   p.nrest = (int)rest_tiles.size();
   p.max_rows_rest = max_rows_rest;
   p.fast_lds_bytes = fast_lds;
+  p.nwide = (int)wide_tiles.size();
+  p.wide_lds_bytes = wide_lds;
+  if (p.nwide) {
+    if (!p.tiles_wide.reserve(wide_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(p.tiles_wide.as<void>(), wide_tiles.data(), wide_tiles.size() * sizeof(LowpassTile),
+                              hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
+      return false;
+  }
   if (p.nfast) {
     if (!p.tiles_fast.reserve(fast_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
     if (!check(hipMemcpyAsync(p.tiles_fast.as<void>(), fast_tiles.data(), fast_tiles.size() * sizeof(LowpassTile),
@@ -758,6 +811,7 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
         return false;
   }
   LowpassArgs a;
+  a.nframes = n_frames;
   a.src = d_in;
   a.src_frame_bytes = in_frame_bytes;
   a.sstride = in_stride;
@@ -773,7 +827,12 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
   a.tile_w = kTileW;
   a.dst_dword_ok = ((uintptr_t)d_out % 4 == 0 && out_stride % 4 == 0 && out_frame_bytes % 4 == 0) ? 1 : 0;
   const bool src_dword_ok = (uintptr_t)d_in % 4 == 0 && in_stride % 4 == 0 && in_frame_bytes % 4 == 0 && w % 4 == 0 && w >= 4;
-  if (p.nfast > 0 && src_dword_ok) {
+  if ((p.nfast > 0 || p.nwide > 0) && src_dword_ok) {
+    a.wide_tiles = p.tiles_wide.as<LowpassTile>();
+    a.nwide = p.nwide;
+    a.wide_lds_bytes = p.wide_lds_bytes;
+    a.taps_sh = p.taps_sh.as<uint32_t>();
+    a.wide_frames = lowpass_frames_;
     a.fast_tiles = p.tiles_fast.as<LowpassTile>();
     a.nfast = p.nfast;
     a.fast_ky = p.fast_ky;
@@ -782,6 +841,11 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
     a.ntiles = p.nrest;
     a.max_rows = p.max_rows_rest;
   } else {
+    a.wide_tiles = nullptr;
+    a.nwide = 0;
+    a.wide_lds_bytes = 0;
+    a.taps_sh = nullptr;
+    a.wide_frames = 1;
     a.fast_tiles = nullptr;
     a.nfast = 0;
     a.fast_ky = 0;

@@ -85,8 +85,9 @@ class VideoFrameTransform {
     int tiles_w = -1, tiles_h = -1;  // plane size the tile lists were built for
     int ntiles = 0, max_rows = 0;    // generic tiles covering EVERY segment (any alignment)
     // when the buffers are dword friendly: fast tiles of the eligible segments + generic tiles of the rest
-    t360::DeviceBuffer tiles_fast, tiles_rest;
+    t360::DeviceBuffer tiles_fast, tiles_rest, tiles_wide, taps_sh;
     int nfast = 0, nrest = 0, max_rows_rest = 0, fast_lds_bytes = 0;
+    int nwide = 0, wide_lds_bytes = 0;  // seg_fast[i] == 2: the segment's runs go to the wide fast path
     bool full_cover = false;
     // LDS-tiled gather: work list planned on the host at init (t360_plan.cpp)
     struct GatherPlan {
@@ -145,6 +146,8 @@ class VideoFrameTransform {
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
   bool use_fast_lowpass_ = true;
+  int lowpass_frames_ = 2;         // frames per workgroup of the wide low-pass path
+  bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path: device side
