@@ -73,7 +73,10 @@ struct SegmentDev {
 };
 constexpr int kWideTapStride = 12;  // dwords per shifted tap variant (zero padded)
 constexpr int kWideMaxNd = 11;      // longest window, in dwords, the wide low-pass path instantiates
-constexpr int kWideTileW = 512, kWideTileH = 32;
+#ifndef T360_LP_TILE_W
+#define T360_LP_TILE_W 512
+#endif
+constexpr int kWideTileW = T360_LP_TILE_W, kWideTileH = 32;  // 1024 / kWideTileW row groups of kWideTileW / 4 lanes
 
 // One unit of low-pass work: a tile of one segment (tiles never straddle segments because the
 // filter kernels change at segment borders).

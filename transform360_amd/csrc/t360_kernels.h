@@ -105,8 +105,6 @@ struct LowpassArgs {
   int nwide;
   int wide_lds_bytes;
   const uint32_t* taps_sh;    // SegmentDev::kxs_off
-  int wide_frames;            // frames one workgroup of the wide path walks with its tile
-  int nframes;                // (set by launch_lowpass)
 };
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
 

@@ -286,6 +286,13 @@ __global__ __launch_bounds__(256) void lowpass_q8_kernel(LowpassArgs a) {
 //     source dwords from byte (px0 - rx - m) on, m = (-rx) & 3, and output pixel j takes its dot products against
 //     the packed taps shifted by m + j bytes: four tap variants (SGPRs, set up by the host) replace 7 of every
 //     8 v_alignbit, ND v_dot4 per pixel and nothing else.
+// two int16 -> two saturated uint8 in bytes 0 and 1 (upper half zero)
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t two_i16) {
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(two_i16));
+  return r;
+}
+
 template <int KY, int ND>
 __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const LowpassTile& t,
                                                  const uint32_t* __restrict__ box, int pitch,
@@ -297,8 +304,9 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int i = 0; i < ND; i++) T[j][i] = kxs[j * kWideTapStride + i];  // scalar loads (per frame: they hit the scalar cache)
-  const int lir = threadIdx.x & 127, grp = threadIdx.x >> 7;
-  const int rpg = (t.h + 1) >> 1;
+  constexpr int kGroups = 1024 / kWideTileW;  // row groups of kWideTileW / 4 lanes
+  const int lir = threadIdx.x & (kWideTileW / 4 - 1), grp = threadIdx.x / (kWideTileW / 4);
+  const int rpg = (t.h + kGroups - 1) / kGroups;
   const int r0 = grp * rpg;  // first output row of this group, relative to the tile
   const int r1 = min(r0 + rpg, t.h);
   if (r0 >= r1 || 4 * lir >= t.w) return;
@@ -337,16 +345,17 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
             c[p] = 1u << 15;
 #pragma unroll
             for (int k = 0; k < KY; k++) c[p] = __umul24(kyv[k], win[(u + 1 + k) % KY][p]) + c[p];
-            c[p] = min(c[p], 0x00ffffffu);  // byte 2 is now sat_u8(c >> 16)
           }
+          // c >> 16 is 0 .. 256: saturate two at a time (v_sat_pk_u8_i16) instead of a v_min per pixel
+          const uint32_t lo = sat_pk_u8_i16(__builtin_amdgcn_perm(c[1], c[0], 0x07060302u));  // [c0 >> 16, c1 >> 16] as i16
+          const uint32_t hi = sat_pk_u8_i16(__builtin_amdgcn_perm(c[3], c[2], 0x07060302u));
+          const uint32_t out = lo | (hi << 16);
           if (dword_out) {
-            const uint32_t lo = __builtin_amdgcn_perm(c[1], c[0], 0x0c0c0602u);  // [c0.b2, c1.b2, 0, 0]
-            const uint32_t hi = __builtin_amdgcn_perm(c[3], c[2], 0x06020c0cu);  // [0, 0, c2.b2, c3.b2]
-            *reinterpret_cast<uint32_t*>(d) = lo | hi;
+            *reinterpret_cast<uint32_t*>(d) = out;
           } else {
 #pragma unroll
             for (int p = 0; p < 4; p++)
-              if (p < npx) d[p] = (uint8_t)(c[p] >> 16);
+              if (p < npx) d[p] = (uint8_t)(out >> (8 * p));
           }
           d += a.dstride;
         }
@@ -356,19 +365,22 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
   }
 }
 
-// The frames of a workgroup's run, one tile: the next frame's rectangle is on its way from memory (in registers)
-// while the current one is filtered out of LDS.  The rectangle starts at a 16-byte aligned source column and the
-// plane is a whole number of 16-byte pieces wide, so a piece is inside its row or entirely outside it: outside
-// pieces are loaded from somewhere harmless and overwritten by the border fix-up (replicate: a splat of the row's
-// first / last byte), which only the tiles at the plane's left and right edge run.
+// One tile of one frame.  The staged rectangle starts at a 16-byte aligned source column and the plane is a whole
+// number of 16-byte pieces wide, so a piece is inside its row or entirely outside it: outside pieces are loaded
+// from somewhere harmless and overwritten by the border fix-up (replicate: a splat of the row's first / last
+// byte), which only the tiles at the plane's left and right edge run.  Pieces are dealt to the 256 threads in
+// linear order, all loads of a thread in flight together.
 template <int KY, int ND>
-__device__ __forceinline__ void lowpass_q8w_frames(const LowpassArgs& a, const LowpassTile& t, const SegmentDev& s,
-                                                   uint32_t* __restrict__ box, int f0, int f1) {
+__device__ __forceinline__ void lowpass_q8w_tile(const LowpassArgs& a, const LowpassTile& t, const SegmentDev& s,
+                                                 uint32_t* __restrict__ box, const uint8_t* __restrict__ src,
+                                                 uint8_t* __restrict__ dst) {
   constexpr int ry = KY >> 1;
-  constexpr int NS = 6;  // staging slots per thread: ceil((32 + 6) rows x 36 pieces / 256 threads)
-  const int rx = s.kx_len >> 1;
-  const uint32_t* kxs = a.taps_sh + s.kxs_off;
-  const int* __restrict__ ky = a.taps_q8 + s.ky_off;
+  // staging slots per thread: ceil((32 + 6) rows x ceil((3 + W/4 + 10) / 4) pieces / 256 threads)
+  constexpr int NS = ((kWideTileH + 6) * ((3 + kWideTileW / 4 + kWideMaxNd - 1 + 3) / 4) + 255) / 256;
+  // (the segment record is workgroup-uniform; say so, or hipcc reads the taps with vector loads into VGPRs)
+  const int rx = __builtin_amdgcn_readfirstlane(s.kx_len) >> 1;
+  const uint32_t* __restrict__ kxs = a.taps_sh + __builtin_amdgcn_readfirstlane(s.kxs_off);
+  const int* __restrict__ ky = a.taps_q8 + __builtin_amdgcn_readfirstlane(s.ky_off);
   uint32_t kyv[KY];
 #pragma unroll
   for (int k = 0; k < KY; k++) kyv[k] = (uint32_t)ky[k];
@@ -377,67 +389,43 @@ __device__ __forceinline__ void lowpass_q8w_frames(const LowpassArgs& a, const L
   const int dxw = (t.x0 - rx - m) >> 2;     // first dword column any lane's window needs (may be < 0)
   const int dx0 = dxw & ~3;                 // first staged dword column: 16-byte aligned
   const int lead = dxw - dx0;
-  const int ndw = lead + ((t.w + 3) >> 2) + s.kxs_nd - 1;
+  const int ndw = lead + ((t.w + 3) >> 2) + __builtin_amdgcn_readfirstlane(s.kxs_nd) - 1;
   const int pitch = (ndw + 3) & ~3, n4 = pitch >> 2;
   const int rows = t.h + 2 * ry;
   const int W4 = a.w >> 2;
   const int last = rows * n4 - 1;
-  int goff[NS], loff[NS];
+  {
+    uint4 v[NS];
+    int loff[NS];
 #pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const int i = min((int)threadIdx.x + 256 * k, last);  // surplus slots repeat the last piece
-    const int r = i / n4, c4 = (i - r * n4) * 4;
-    loff[k] = r * pitch + c4;
-    goff[k] = clampi(t.y0 - ry + r, 0, a.h - 1) * a.sstride + clampi(dx0 + c4, 0, W4 - 4) * 4;
-  }
-  const int nleft = dx0 < 0 ? -dx0 : 0;                         // staged dwords left of the plane
-  const int first_right = W4 - dx0;                             // first staged dword right of the plane
-  const bool edge = nleft > 0 || first_right < pitch;           // workgroup-uniform
-  uint4 v0, v1, v2, v3, v4, v5;
-  static_assert(NS == 6, "the six staging registers below");
-#define T360_LD(k, src) *reinterpret_cast<const uint4*>((src) + goff[k])
-#define T360_FETCH(f)                                                          \
-  {                                                                            \
-    const uint8_t* __restrict__ src = a.src + (size_t)(f) * a.src_frame_bytes; \
-    v0 = T360_LD(0, src);                                                      \
-    v1 = T360_LD(1, src);                                                      \
-    v2 = T360_LD(2, src);                                                      \
-    v3 = T360_LD(3, src);                                                      \
-    v4 = T360_LD(4, src);                                                      \
-    v5 = T360_LD(5, src);                                                      \
-  }
-  T360_FETCH(f0)
-  for (int f = f0; f < f1; f++) {
-    if (f > f0) __syncthreads();  // everyone has left the previous frame's rectangle
-    *reinterpret_cast<uint4*>(box + loff[0]) = v0;
-    *reinterpret_cast<uint4*>(box + loff[1]) = v1;
-    *reinterpret_cast<uint4*>(box + loff[2]) = v2;
-    *reinterpret_cast<uint4*>(box + loff[3]) = v3;
-    *reinterpret_cast<uint4*>(box + loff[4]) = v4;
-    *reinterpret_cast<uint4*>(box + loff[5]) = v5;
-    __syncthreads();
-    if (edge) {
-      if ((int)threadIdx.x < rows) {
-        uint32_t* __restrict__ row = box + (int)threadIdx.x * pitch;
-        if (nleft > 0) {
-          const uint32_t e = (row[nleft] & 0xffu) * 0x01010101u;
-          for (int j = 0; j < nleft; j++) row[j] = e;
-        }
-        if (first_right < pitch) {
-          const uint32_t e = (row[first_right - 1] >> 24) * 0x01010101u;
-          for (int j = first_right; j < pitch; j++) row[j] = e;
-        }
-      }
-      __syncthreads();
+    for (int k = 0; k < NS; k++) {
+      const int i = min((int)threadIdx.x + 256 * k, last);  // surplus slots repeat the last piece
+      const int r = i / n4, c4 = (i - r * n4) * 4;
+      loff[k] = r * pitch + c4;
+      v[k] = *reinterpret_cast<const uint4*>(src + (size_t)clampi(t.y0 - ry + r, 0, a.h - 1) * a.sstride +
+                                             clampi(dx0 + c4, 0, W4 - 4) * 4);
     }
-    if (f + 1 < f1) T360_FETCH(f + 1)
-    // the packed taps are re-read per frame (scalar cache hits): hoisted out of this loop they would not fit the
-    // SGPR file next to the loop's own state, and hipcc would keep them in 44 VGPRs
-    asm volatile("" : "+s"(kxs));
-    lowpass_q8w_rows<KY, ND>(a, t, box + lead, pitch, kxs, kyv, a.dst + (size_t)f * a.dst_frame_bytes);
+#pragma unroll
+    for (int k = 0; k < NS; k++) *reinterpret_cast<uint4*>(box + loff[k]) = v[k];
   }
-#undef T360_FETCH
-#undef T360_LD
+  __syncthreads();
+  const int nleft = dx0 < 0 ? -dx0 : 0;    // staged dwords left of the plane
+  const int first_right = W4 - dx0;        // first staged dword right of the plane
+  if (nleft > 0 || first_right < pitch) {  // workgroup-uniform
+    if ((int)threadIdx.x < rows) {
+      uint32_t* __restrict__ row = box + (int)threadIdx.x * pitch;
+      if (nleft > 0) {
+        const uint32_t e = (row[nleft] & 0xffu) * 0x01010101u;
+        for (int j = 0; j < nleft; j++) row[j] = e;
+      }
+      if (first_right < pitch) {
+        const uint32_t e = (row[first_right - 1] >> 24) * 0x01010101u;
+        for (int j = first_right; j < pitch; j++) row[j] = e;
+      }
+    }
+    __syncthreads();
+  }
+  lowpass_q8w_rows<KY, ND>(a, t, box + lead, pitch, kxs, kyv, dst);
 }
 
 template <int KY>
@@ -451,17 +439,18 @@ __global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
   if (ti >= min((xcd + 1) * per, a.nwide)) return;
   const LowpassTile t = a.wide_tiles[ti];
   const SegmentDev s = a.segs[t.seg];
-  const int f0 = blockIdx.y * a.wide_frames, f1 = min(f0 + a.wide_frames, a.nframes);
+  const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.y * a.src_frame_bytes;
+  uint8_t* __restrict__ dst = a.dst + (size_t)blockIdx.y * a.dst_frame_bytes;
   // instantiated per window length
-  const int nd = s.kxs_nd;
+  const int nd = __builtin_amdgcn_readfirstlane(s.kxs_nd);
   if (nd <= 3)
-    lowpass_q8w_frames<KY, 3>(a, t, s, box, f0, f1);
+    lowpass_q8w_tile<KY, 3>(a, t, s, box, src, dst);
   else if (nd <= 5)
-    lowpass_q8w_frames<KY, 5>(a, t, s, box, f0, f1);
+    lowpass_q8w_tile<KY, 5>(a, t, s, box, src, dst);
   else if (nd <= 8)
-    lowpass_q8w_frames<KY, 8>(a, t, s, box, f0, f1);
+    lowpass_q8w_tile<KY, 8>(a, t, s, box, src, dst);
   else
-    lowpass_q8w_frames<KY, kWideMaxNd>(a, t, s, box, f0, f1);
+    lowpass_q8w_tile<KY, kWideMaxNd>(a, t, s, box, src, dst);
 }
 
 }  // namespace
@@ -469,14 +458,11 @@ __global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream) {
   if (nframes <= 0) return hipSuccess;
   if (a.nwide > 0) {
-    LowpassArgs w = a;
-    w.nframes = nframes;
-    if (w.wide_frames < 1) w.wide_frames = 1;
-    const dim3 grid(8 * ((a.nwide + 7) / 8), (nframes + w.wide_frames - 1) / w.wide_frames, 1);
+    const dim3 grid(8 * ((a.nwide + 7) / 8), nframes, 1);
     switch (a.fast_ky) {
-      case 3: hipLaunchKernelGGL(lowpass_q8w_kernel<3>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, w); break;
-      case 5: hipLaunchKernelGGL(lowpass_q8w_kernel<5>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, w); break;
-      case 7: hipLaunchKernelGGL(lowpass_q8w_kernel<7>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, w); break;
+      case 3: hipLaunchKernelGGL(lowpass_q8w_kernel<3>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, a); break;
+      case 5: hipLaunchKernelGGL(lowpass_q8w_kernel<5>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, a); break;
+      case 7: hipLaunchKernelGGL(lowpass_q8w_kernel<7>, grid, dim3(256), (size_t)a.wide_lds_bytes, stream, a); break;
       default: return hipErrorInvalidValue;
     }
     hipError_t e = hipGetLastError();

@@ -202,7 +202,6 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (getenv("T360_NO_TILED")) use_tiled_ = false;
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
   if (getenv("T360_NO_WIDE_LOWPASS")) use_wide_lowpass_ = false;
-  if (const char* e = getenv("T360_LOWPASS_FRAMES")) lowpass_frames_ = std::max(1, atoi(e));
 #endif
   ok_ = true;
 }
@@ -811,7 +810,6 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
         return false;
   }
   LowpassArgs a;
-  a.nframes = n_frames;
   a.src = d_in;
   a.src_frame_bytes = in_frame_bytes;
   a.sstride = in_stride;
@@ -832,7 +830,6 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
     a.nwide = p.nwide;
     a.wide_lds_bytes = p.wide_lds_bytes;
     a.taps_sh = p.taps_sh.as<uint32_t>();
-    a.wide_frames = lowpass_frames_;
     a.fast_tiles = p.tiles_fast.as<LowpassTile>();
     a.nfast = p.nfast;
     a.fast_ky = p.fast_ky;
@@ -845,7 +842,6 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
     a.nwide = 0;
     a.wide_lds_bytes = 0;
     a.taps_sh = nullptr;
-    a.wide_frames = 1;
     a.fast_tiles = nullptr;
     a.nfast = 0;
     a.fast_ky = 0;

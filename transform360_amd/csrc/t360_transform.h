@@ -146,7 +146,6 @@ class VideoFrameTransform {
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
   bool use_fast_lowpass_ = true;
-  int lowpass_frames_ = 2;         // frames per workgroup of the wide low-pass path
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
