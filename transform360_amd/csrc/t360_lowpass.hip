@@ -293,17 +293,22 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t two_i16) {
   return r;
 }
 
-template <int KY, int ND>
+// KX > 0: the exact number of horizontal taps is a compile-time constant, so the all-zero dwords of a shifted tap
+// variant (which dwords they are follows from KX alone) cost nothing: 6 instead of 12 v_dot4 per 4 pixels for 3
+// taps, 8 for 5, 10 for 7, 16 instead of 20 for 13.  KX == 0: any length whose window fits ND dwords.
+template <int KY, int ND, int KX>
 __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const LowpassTile& t,
                                                  const uint32_t* __restrict__ box, int pitch,
                                                  const uint32_t* __restrict__ kxs, const uint32_t (&kyv)[KY],
                                                  uint8_t* __restrict__ dst) {
   constexpr int ry = KY >> 1;
+  constexpr int M = KX > 0 ? (4 - (KX / 2) % 4) % 4 : 0;  // the host's m for this length
+  auto used = [](int j, int i) { return KX == 0 || (i >= (M + j) / 4 && i <= (M + j + KX - 1) / 4); };
   uint32_t T[4][ND];
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int i = 0; i < ND; i++) T[j][i] = kxs[j * kWideTapStride + i];  // scalar loads (per frame: they hit the scalar cache)
+    for (int i = 0; i < ND; i++) T[j][i] = used(j, i) ? kxs[j * kWideTapStride + i] : 0u;  // scalar loads
   constexpr int kGroups = 1024 / kWideTileW;  // row groups of kWideTileW / 4 lanes
   const int lir = threadIdx.x & (kWideTileW / 4 - 1), grp = threadIdx.x / (kWideTileW / 4);
   const int rpg = (t.h + kGroups - 1) / kGroups;
@@ -335,7 +340,8 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
         for (int p = 0; p < 4; p++) {
           uint32_t acc = 0u;
 #pragma unroll
-          for (int i = 0; i < ND; i++) acc = __builtin_amdgcn_udot4(D[i], T[p][i], acc, false);
+          for (int i = 0; i < ND; i++)
+            if (used(p, i)) acc = __builtin_amdgcn_udot4(D[i], T[p][i], acc, false);
           win[u][p] = acc;
         }
         if (r >= r0 + 2 * ry) {  // the window of output row r - 2 ry is complete: slots u+1 .. u (mod KY)
@@ -370,7 +376,7 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
 // from somewhere harmless and overwritten by the border fix-up (replicate: a splat of the row's first / last
 // byte), which only the tiles at the plane's left and right edge run.  Pieces are dealt to the 256 threads in
 // linear order, all loads of a thread in flight together.
-template <int KY, int ND>
+template <int KY, int ND, int KX>
 __device__ __forceinline__ void lowpass_q8w_tile(const LowpassArgs& a, const LowpassTile& t, const SegmentDev& s,
                                                  uint32_t* __restrict__ box, const uint8_t* __restrict__ src,
                                                  uint8_t* __restrict__ dst) {
@@ -425,7 +431,7 @@ __device__ __forceinline__ void lowpass_q8w_tile(const LowpassArgs& a, const Low
     }
     __syncthreads();
   }
-  lowpass_q8w_rows<KY, ND>(a, t, box + lead, pitch, kxs, kyv, dst);
+  lowpass_q8w_rows<KY, ND, KX>(a, t, box + lead, pitch, kxs, kyv, dst);
 }
 
 template <int KY>
@@ -441,16 +447,23 @@ __global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
   const SegmentDev s = a.segs[t.seg];
   const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.y * a.src_frame_bytes;
   uint8_t* __restrict__ dst = a.dst + (size_t)blockIdx.y * a.dst_frame_bytes;
-  // instantiated per window length
-  const int nd = __builtin_amdgcn_readfirstlane(s.kxs_nd);
-  if (nd <= 3)
-    lowpass_q8w_tile<KY, 3>(a, t, s, box, src, dst);
-  else if (nd <= 5)
-    lowpass_q8w_tile<KY, 5>(a, t, s, box, src, dst);
-  else if (nd <= 8)
-    lowpass_q8w_tile<KY, 8>(a, t, s, box, src, dst);
-  else
-    lowpass_q8w_tile<KY, kWideMaxNd>(a, t, s, box, src, dst);
+  // instantiated per tap count for the short kernels, per window length for the rest
+  const int nd = __builtin_amdgcn_readfirstlane(s.kxs_nd), kx = __builtin_amdgcn_readfirstlane(s.kx_len);
+  switch (kx) {
+    case 3: lowpass_q8w_tile<KY, 3, 3>(a, t, s, box, src, dst); break;
+    case 5: lowpass_q8w_tile<KY, 3, 5>(a, t, s, box, src, dst); break;
+    case 7: lowpass_q8w_tile<KY, 3, 7>(a, t, s, box, src, dst); break;
+    case 9: lowpass_q8w_tile<KY, 3, 9>(a, t, s, box, src, dst); break;
+    case 11: lowpass_q8w_tile<KY, 5, 11>(a, t, s, box, src, dst); break;
+    case 13: lowpass_q8w_tile<KY, 5, 13>(a, t, s, box, src, dst); break;
+    default:
+      if (nd <= 5)
+        lowpass_q8w_tile<KY, 5, 0>(a, t, s, box, src, dst);
+      else if (nd <= 8)
+        lowpass_q8w_tile<KY, 8, 0>(a, t, s, box, src, dst);
+      else
+        lowpass_q8w_tile<KY, kWideMaxNd, 0>(a, t, s, box, src, dst);
+  }
 }
 
 }  // namespace
