@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors in tests/golden/ FROM THE REFERENCE'S OWN CODE.
+"""Generate the golden vectors in tests/golden/: maps and filter configurations FROM THE REFERENCE'S OWN CODE, frame
+hashes from the reference's frame path over the oracle's cv:: restatement (SHIM-GENERATED, see below).
 
 Run in the builder container (where /root/reference is mounted):
 

@@ -1,6 +1,10 @@
-"""CPU suite: the oracle against the committed golden vectors (made by the reference's own
-code, tests/golden/make_golden.py) and -- where /root/reference is mounted -- against the
-reference build itself (oracle/_ref), entry by entry."""
+"""CPU suite: the oracle against the committed golden vectors (tests/golden/make_golden.py) and -- where
+/root/reference is mounted -- against the reference build itself (oracle/_ref), entry by entry.
+
+Provenance of the vectors: maps.json and lowpass.json come from the reference's own projection and filter-config
+code; frames.json is SHIM-GENERATED -- the reference's frame path ran, but its cv::remap / cv::sepFilter2D /
+cv::resize calls were bound to the oracle's restatement of OpenCV, so those vectors pin the orchestration (segments,
+eyes, border modes, resize branch) and NOT OpenCV's arithmetic (parity unpinned at that boundary)."""
 import numpy as np
 import pytest
 
@@ -96,7 +100,7 @@ def test_cfg3_integer_kernels_match_survey_appendix_b(oracle_mod):
 
 
 @pytest.mark.parametrize("name", sorted(ALL_FRAMES))
-def test_frame_path_matches_golden(name, oracle_mod, golden):
+def test_frame_path_matches_shim_generated_golden(name, oracle_mod, golden):
     O = oracle_mod
     ov, dims, pin, pout = ALL_FRAMES[name]
     in_w, in_h, out_w, out_h = dims
