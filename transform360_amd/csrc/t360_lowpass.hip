@@ -310,7 +310,8 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
 #pragma unroll
     for (int i = 0; i < ND; i++) T[j][i] = used(j, i) ? kxs[j * kWideTapStride + i] : 0u;  // scalar loads
   constexpr int kGroups = 1024 / kWideTileW;  // row groups of kWideTileW / 4 lanes
-  const int lir = threadIdx.x & (kWideTileW / 4 - 1), grp = threadIdx.x / (kWideTileW / 4);
+  // a row group is a whole number of waves: its row range is wave-uniform (scalar loop control)
+  const int lir = threadIdx.x & (kWideTileW / 4 - 1), grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (kWideTileW / 4));
   const int rpg = (t.h + kGroups - 1) / kGroups;
   const int r0 = grp * rpg;  // first output row of this group, relative to the tile
   const int r1 = min(r0 + rpg, t.h);
