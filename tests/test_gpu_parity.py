@@ -80,13 +80,30 @@ def test_unsupported_request_is_refused_not_faked(T):
     from transform360_amd.abi import LAYOUT_N
     with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_N)) as t:
         assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
-    # a plane handed over with another output size than its map was generated for has no resize plan: refused
-    with T.VideoFrameTransform(filter_defaults(width_scale_factor=0.5, height_scale_factor=0.5)) as t:
+
+
+def test_output_size_given_at_call_time_is_resized_like_the_reference(T, oracle_mod):
+    # transformPlane resizes the warped image to WHATEVER output size the call names (VideoFrameTransform.cpp:735-737,
+    # 759-776), not only to the size generateMapForPlane was told: here a 192x128 map (factors 0.5) lands in a
+    # 200x100 plane -- INTER_AREA enlarging in x, shrinking in y
+    O = oracle_mod
+    ctx = filter_defaults(width_scale_factor=0.5, height_scale_factor=0.5, enable_low_pass_filter=0)
+    o = O.Oracle(ctx, threads=2)
+    src = np.random.default_rng(11).integers(0, 256, (512, 1024), dtype=np.uint8)
+    want = np.zeros((100, 200), np.uint8)
+    assert o.generateMapForPlane(1024, 512, 384, 256, 0) and o.transformFramePlane(src, want, 0, 0)
+    with T.VideoFrameTransform(ctx) as t:
         assert t.generateMapForPlane(1024, 512, 384, 256, 0)
-        src = dev(np.zeros((512, 1024), np.uint8))
-        dst = dev(np.zeros((100, 200), np.uint8))
+        dsrc, ddst = dev(src), dev(np.zeros((100, 200), np.uint8))
         _ready()
-        assert not t.transformFramePlane(src, dst, 0)
+        assert t.transformFramePlane(dsrc, ddst, 0) and t.synchronize()
+        assert np.array_equal(ddst.cpu().numpy(), want)
+        # and back to the size the map was generated for (the tables follow the call)
+        want2 = np.zeros((256, 384), np.uint8)
+        assert o.transformFramePlane(src, want2, 0, 0)
+        ddst2 = dev(np.zeros((256, 384), np.uint8))
+        assert t.transformFramePlane(dsrc, ddst2, 0) and t.synchronize()
+        assert np.array_equal(ddst2.cpu().numpy(), want2)
 
 
 # ---------------------------------------------------------------- low-pass configuration
@@ -234,6 +251,28 @@ def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
     _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0, interpolation_alg=interp), n=3, extra_pad=0)
     # and the general gather for buffers that are not (odd padding)
     _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0, interpolation_alg=interp), n=2, extra_pad=40)
+
+
+def test_alpha_plane_quirk_matches(T, oracle_mod):
+    """The filter hands a 4th (alpha) plane to map index 0 with CHROMA dimensions (vf_transform360.c:368-397): the luma
+    map then samples a plane a quarter of its size (BORDER_WRAP), the output takes the resize branch, and with the
+    low-pass on every segment that does not fit the smaller plane is skipped with a message.  Same bytes as the oracle
+    (which agrees with the reference build on this case, tests/test_oracle.py)."""
+    import torch
+    O = oracle_mod
+    for ov in (dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4)):
+        ctx = filter_defaults(**ov)
+        o = O.Oracle(ctx, threads=2)
+        src = np.random.default_rng(7).integers(0, 256, (120, 240), dtype=np.uint8)
+        want = np.full((64, 96), 0x5A, np.uint8)
+        assert o.generateMapForPlane(480, 240, 192, 128, 0) and o.transformFramePlane(src, want, 0, 3)
+        with T.VideoFrameTransform(ctx) as t:
+            assert t.generateMapForPlane(480, 240, 192, 128, 0)
+            dsrc = torch.from_numpy(src).cuda()
+            ddst = torch.full((64, 96), 0x5A, dtype=torch.uint8, device="cuda")
+            _ready()
+            assert t.transformFramePlane(dsrc, ddst, 0, 3) and t.synchronize()
+            assert np.array_equal(ddst.cpu().numpy(), want)
 
 
 # The shipped library reads no environment.  The instrumented build (make instr: -DT360_INSTRUMENT) does, for A/B

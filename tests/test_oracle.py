@@ -181,3 +181,18 @@ def test_unknown_interpolation_writes_nothing(oracle_mod):
     dst = np.full((32, 48), 9, np.uint8)
     assert o.transformFramePlane(np.zeros((64, 128), np.uint8), dst, 0)
     assert (dst == 9).all()
+
+
+def test_alpha_plane_quirk_oracle_equals_reference(oracle_mod):
+    """4th plane of a yuva420p frame: map index 0 with chroma dimensions (vf_transform360.c:368-397)."""
+    O = oracle_mod
+    if not O.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available here")
+    for ov in (dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4)):
+        ctx = filter_defaults(**ov)
+        o, r = O.Oracle(ctx, threads=2), O.Ref(ctx)
+        src = np.random.default_rng(7).integers(0, 256, (120, 240), dtype=np.uint8)
+        a, b = np.full((64, 96), 0x5A, np.uint8), np.full((64, 96), 0x5A, np.uint8)
+        assert o.generateMapForPlane(480, 240, 192, 128, 0) and r.generateMapForPlane(480, 240, 192, 128, 0)
+        assert o.transformFramePlane(src, a, 0, 3) and r.transformFramePlane(src, b, 0, 3)
+        assert np.array_equal(a, b)

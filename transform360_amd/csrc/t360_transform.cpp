@@ -553,7 +553,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   }
   // host vectors above go out of scope: finish the uploads (init-time only)
   if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
-  if (!buildResizePlan(p)) return false;
+  if (!buildResizePlan(p, p.out_w, p.out_h)) return false;
   p.valid = true;
   return true;
 }
@@ -561,13 +561,15 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
 // cv::resize(..., INTER_AREA) from the warp-map size to the output size (reference :770-776);
 // which of OpenCV's code paths applies and, for fractional factors, its DecimateAlpha tables
 // (resize.cpp computeResizeAreaTab, evaluated in double like OpenCV does).
-bool VideoFrameTransform::buildResizePlan(PlaneState& p) {
+bool VideoFrameTransform::buildResizePlan(PlaneState& p, int dw, int dh) {
   PlaneState::ResizePlan& r = p.resize;
-  r.needed = p.map_w != p.out_w || p.map_h != p.out_h;
+  r.dw = dw;
+  r.dh = dh;
+  r.needed = p.map_w != dw || p.map_h != dh;
   r.supported = false;
   r.iscale_x = r.iscale_y = 0;
   if (!r.needed) return true;
-  const int sw = p.map_w, sh = p.map_h, dw = p.out_w, dh = p.out_h;
+  const int sw = p.map_w, sh = p.map_h;
   if (dw <= 0 || dh <= 0) return true;
   const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
   r.supported = true;
@@ -719,11 +721,14 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
         const size_t n = p.filter.segments.size();
         const bool continues_prev = i > 0 && p.seg_fast[i - 1] && same_run(p.filter.segments[i - 1], s);
         if (!continues_prev) {
+          // the run = this segment and the members that follow it AND still fit the plane (a plane smaller than the one
+          // the segments were computed for -- the filter's alpha-plane quirk -- keeps the members that fit, like the
+          // reference, which range-checks every segment on its own)
           int run_w = s.width;
-          for (size_t k = i + 1; k < n && p.seg_fast[k] && same_run(p.filter.segments[k - 1], p.filter.segments[k]); k++)
+          for (size_t k = i + 1; k < n && p.seg_fast[k] && same_run(p.filter.segments[k - 1], p.filter.segments[k]) &&
+                                 L + run_w + p.filter.segments[k].width <= w;
+               k++)
             run_w += p.filter.segments[k].width;
-          bool inside = L + run_w <= w;  // every member was range-checked above only one at a time
-          if (!inside) run_w = s.width;
           if (p.seg_fast[i] == 2 && L % 4 == 0 && w % 16 == 0 && use_wide_lowpass_) {
             // wide tiles, row-major: <= 512 x 32 px (2 row groups of 128 lanes x 4 px)
             const int nd = ((int)s.kx_q8.size() + (4 - ((int)s.kx_q8.size() / 2) % 4) % 4 + 6) / 4;
@@ -861,13 +866,15 @@ bool VideoFrameTransform::runPlanesScaled(const PlaneJob* jobs, int njobs, int n
   std::vector<int> strides((size_t)njobs);
   size_t total = 0;
   for (int k = 0; k < njobs; k++) {
-    const PlaneState& p = planes_[jobs[k].idx];
-    if (jobs[k].out_w != p.out_w || jobs[k].out_h != p.out_h || !p.resize.needed) {
-      // the reference resizes to whatever size it is handed; the plan here is for the size given
-      // to generateMapForPlane, which is what the filter passes (vf_transform360.c:368-397)
-      printf("Could not transform the plane %d. Error: output size differs from the one the map was generated for\n",
-             jobs[k].image_plane);
-      return false;
+    PlaneState& p = planes_[jobs[k].idx];
+    if (jobs[k].out_w != p.resize.dw || jobs[k].out_h != p.resize.dh) {
+      // the reference resizes to whatever size it is handed (:735-737): normally the size given to generateMapForPlane,
+      // but the filter passes an alpha plane to map 0 with chroma dimensions (vf_transform360.c:368-397).  The tables
+      // are rebuilt when the target size changes (a caller alternating two sizes on one map pays that per call).
+      if (jobs[k].out_w <= 0 || jobs[k].out_h <= 0 || !buildResizePlan(p, jobs[k].out_w, jobs[k].out_h)) {
+        printf("Could not transform the plane %d. Error: no resize plan for this output size\n", jobs[k].image_plane);
+        return false;
+      }
     }
     if (!p.resize.supported) {
       printf("Could not transform the plane %d. Error: no resize plan for this output size\n", jobs[k].image_plane);

@@ -74,6 +74,7 @@ class VideoFrameTransform {
     // INTER_AREA shrink map_w x map_h -> out_w x out_h (only when the scale factors are not 1)
     struct ResizePlan {
       bool needed = false, supported = false, linear = false;
+      int dw = -1, dh = -1;  // the output size the tables are for
       int iscale_x = 0, iscale_y = 0, xmax = 0;
       t360::DeviceBuffer xofs, x_si, x_alpha, yofs, y_si, y_alpha;
     } resize;
@@ -115,7 +116,7 @@ class VideoFrameTransform {
   };
   bool runPlanes(const PlaneJob* jobs, int njobs, int n_frames);
   bool runPlanesScaled(const PlaneJob* jobs, int njobs, int n_frames);
-  bool buildResizePlan(PlaneState& p);
+  bool buildResizePlan(PlaneState& p, int dw, int dh);
   bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
                   int imagePlaneIndex, hipStream_t stream);
