@@ -22,7 +22,7 @@
 enum { AV_LOG_ERROR = 16, AV_LOG_INFO = 32, AV_LOG_VERBOSE = 40 };
 enum AVMediaType { AVMEDIA_TYPE_VIDEO = 0 };
 enum { AV_CLASS_CATEGORY_FILTER = 4 };
-enum AVPixelFormat { AV_PIX_FMT_YUV420P = 0, AV_PIX_FMT_GRAY8 = 8, AV_PIX_FMT_YUV444P = 5, AV_PIX_FMT_YUV422P = 4 };
+enum AVPixelFormat { AV_PIX_FMT_YUV420P = 0, AV_PIX_FMT_GRAY8 = 8, AV_PIX_FMT_YUV444P = 5, AV_PIX_FMT_YUV422P = 4, AV_PIX_FMT_YUVA420P = 33 };
 
 enum AVOptionType {
   AV_OPT_TYPE_FLAGS, AV_OPT_TYPE_INT, AV_OPT_TYPE_INT64, AV_OPT_TYPE_DOUBLE, AV_OPT_TYPE_FLOAT, AV_OPT_TYPE_STRING,

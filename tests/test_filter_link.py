@@ -78,3 +78,28 @@ def test_verbatim_filter_runs_and_matches_oracle(opts, ov, tmp_path, oracle_mod)
             got = data[pos:pos + ow * oh].reshape(oh, ow)
             pos += ow * oh
             assert np.array_equal(got, want), "frame %d plane %d differs from the oracle" % (k, p)
+
+
+@pytest.mark.gpu
+def test_verbatim_filter_alpha_plane_quirk(tmp_path, oracle_mod):
+    """yuva420p through the unmodified filter: plane 3 goes to map 0 with chroma dimensions (vf_transform360.c:368-397),
+    i.e. the top-left quarter of the full-size alpha plane is sampled with the LUMA map and resized."""
+    from transform360_amd.handler import noise_bytes
+    exe = _harness()
+    in_w, in_h = 1280, 640
+    raw = tmp_path / "out.raw"
+    r = subprocess.run([exe, str(in_w), str(in_h), "420a", "1", str(raw), "cube_edge_length=128", "enable_low_pass_filter=0"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    out_w, out_h = (int(v) for v in r.stdout.splitlines()[0].split()[1:3])
+    o = oracle_mod.Oracle(filter_defaults(interpolation_alg=CUBIC, enable_low_pass_filter=0), threads=4)
+    cw, ch = chroma_dims(in_w, in_h)
+    ocw, och = chroma_dims(out_w, out_h)
+    assert o.generateMapForPlane(in_w, in_h, out_w, out_h, 0) and o.generateMapForPlane(cw, ch, ocw, och, 1)
+    data = np.fromfile(raw, np.uint8)
+    assert data.size == out_w * out_h + 3 * ocw * och
+    alpha = data[out_w * out_h + 2 * ocw * och:].reshape(och, ocw)
+    full = noise_bytes(in_w * in_h, 0x360 ^ (3 << 36)).reshape(in_h, in_w)
+    want = np.zeros((och, ocw), np.uint8)
+    assert o.transformFramePlane(np.ascontiguousarray(full[:ch, :cw]), want, 0, 3)
+    assert np.array_equal(alpha, want)
