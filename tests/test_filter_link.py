@@ -103,3 +103,30 @@ def test_verbatim_filter_alpha_plane_quirk(tmp_path, oracle_mod):
     want = np.zeros((och, ocw), np.uint8)
     assert o.transformFramePlane(np.ascontiguousarray(full[:ch, :cw]), want, 0, 3)
     assert np.array_equal(alpha, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,shift,planes", [("444", (0, 0), 3), ("gray", (0, 0), 1)])
+def test_verbatim_filter_other_pixel_formats(fmt, shift, planes, tmp_path, oracle_mod):
+    """yuv444p (chroma map = luma shape) and gray (one plane) through the unmodified filter."""
+    from transform360_amd.handler import noise_bytes
+    exe = _harness()
+    in_w, in_h = 640, 320
+    raw = tmp_path / "out.raw"
+    r = subprocess.run([exe, str(in_w), str(in_h), fmt, "1", str(raw), "cube_edge_length=96"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    out_w, out_h = (int(v) for v in r.stdout.splitlines()[0].split()[1:3])
+    o = oracle_mod.Oracle(filter_defaults(interpolation_alg=CUBIC), threads=4)
+    cw, ch = chroma_dims(in_w, in_h, *shift)
+    ocw, och = chroma_dims(out_w, out_h, *shift)
+    assert o.generateMapForPlane(in_w, in_h, out_w, out_h, 0) and o.generateMapForPlane(cw, ch, ocw, och, 1)
+    data = np.fromfile(raw, np.uint8)
+    pos = 0
+    for p in range(planes):
+        iw, ih, ow, oh = (in_w, in_h, out_w, out_h) if p == 0 else (cw, ch, ocw, och)
+        src = noise_bytes(iw * ih, 0x360 ^ (p << 36)).reshape(ih, iw)
+        want = np.zeros((oh, ow), np.uint8)
+        assert o.transformFramePlane(src, want, 1 if p else 0, p)
+        assert np.array_equal(data[pos:pos + ow * oh].reshape(oh, ow), want), "plane %d" % p
+        pos += ow * oh
+    assert pos == data.size
