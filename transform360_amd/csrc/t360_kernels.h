@@ -59,7 +59,7 @@ struct TiledArgs {
   int groups;               // frame groups = ceil(nframes / frames_per_block): work items per tile
   int tail_percent;         // the last tail_percent % of every XCD's tiles use runs of tail_frames frames instead
   int tail_frames, tail_groups;
-  int direct_blocks;        // work items reserved for direct tiles: 8 * groups * (most direct tiles of one pole of one plane)
+  int direct_blocks;        // work items reserved for direct tiles: total_direct * groups, rounded up to a multiple of 8
   int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
   int ring_kb;              // LDS per workgroup in KiB and waves per workgroup (4 or 8): select the kernel instantiation
   int waves;

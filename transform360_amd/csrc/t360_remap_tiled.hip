@@ -582,18 +582,18 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
 // quadrant of longitudes): one pixel per lane, KS*KS independent byte loads in flight.
 template <int KS>
 __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, int f0, int f1) {
-  const int tid = threadIdx.x;
-  if (tid >= 256) return;  // 16x16 pixels
+  // 16x16 pixels on lanes 0..255; in a workgroup of 8 waves lanes 256..511 take every other group of frames
+  const int tid = threadIdx.x & 255, part = threadIdx.x >> 8, nparts = (int)blockDim.x >> 8;
   const int ox = t.ox + (tid & 15), oy = t.oy + (tid >> 4);
   if (ox >= pl.dw || oy >= pl.dh) return;
   const LutEntry e = pl.lut[(size_t)oy * pl.dw + ox];
   uint8_t* __restrict__ d = pl.dst + (size_t)oy * pl.dstride + ox;
   if constexpr (KS == 2 || KS == 4) {
     // Row offsets and weights are the same for every frame: set up once.  A stencil row is ONE (unaligned) dword
-    // load unless it crosses the +-180 degree seam, and two frames' loads are in flight together: a quarter of the
-    // L2 requests of byte loads, which matters because these few tiles would otherwise issue a third of the
-    // kernel's L2 requests.
+    // load unless it crosses the +-180 degree seam, and NF frames' loads are in flight together.  These few tiles
+    // hold a workgroup slot (and its LDS) for as long as they take, so they are worth making quick.
     constexpr int H = KS / 2 - 1, KK = KS * KS;
+    constexpr int NF = 4;  // frames in flight per lane
     int roff[KS], w[KK];
     const int16_t* __restrict__ wt = a.wtab + (size_t)e.frac * KK;
     const int x0 = (int)e.ix - H;
@@ -610,34 +610,32 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
     // the frame loop once per case (not a branch per row: the loads of an iteration must all be in flight together)
     auto frames = [&](auto contig) {
       constexpr bool CONTIG = decltype(contig)::value;
-      for (int f = f0; f < f1; f += 2) {
-        const uint8_t* __restrict__ s0 = pl.src + (size_t)f * pl.src_frame_bytes;
-        const uint8_t* __restrict__ s1 = s0 + (f + 1 < f1 ? pl.src_frame_bytes : 0);
-        uint32_t v0[KS], v1[KS];
+      for (int f = f0 + part * NF; f < f1; f += NF * nparts) {
+        uint32_t v[NF][KS];
 #pragma unroll
-        for (int r = 0; r < KS; r++) {
-          if (CONTIG) {
-            __builtin_memcpy(&v0[r], s0 + roff[r] + x0, 4);
-            __builtin_memcpy(&v1[r], s1 + roff[r] + x0, 4);
-          } else {
-            v0[r] = v1[r] = 0;
+        for (int k = 0; k < NF; k++) {
+          // frames past the end repeat the last one (their loads hit the same lines; nothing is stored for them)
+          const uint8_t* __restrict__ sf = pl.src + (size_t)min(f + k, f1 - 1) * pl.src_frame_bytes;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-              v0[r] |= (uint32_t)s0[roff[r] + xo[c]] << (8 * c);
-              v1[r] |= (uint32_t)s1[roff[r] + xo[c]] << (8 * c);
+          for (int r = 0; r < KS; r++) {
+            if (CONTIG) {
+              __builtin_memcpy(&v[k][r], sf + roff[r] + x0, 4);
+            } else {
+              v[k][r] = 0;
+#pragma unroll
+              for (int c = 0; c < 4; c++) v[k][r] |= (uint32_t)sf[roff[r] + xo[c]] << (8 * c);
             }
           }
         }
-        int sum0 = 1 << (kCoefBits - 1), sum1 = sum0;
 #pragma unroll
-        for (int r = 0; r < KS; r++)
+        for (int k = 0; k < NF; k++) {
+          int sum = 1 << (kCoefBits - 1);
 #pragma unroll
-          for (int c = 0; c < KS; c++) {
-            sum0 += (int)((v0[r] >> (8 * c)) & 255u) * w[r * KS + c];
-            sum1 += (int)((v1[r] >> (8 * c)) & 255u) * w[r * KS + c];
-          }
-        d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum0 >> kCoefBits);
-        if (f + 1 < f1) d[(size_t)(f + 1) * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum1 >> kCoefBits);
+          for (int r = 0; r < KS; r++)
+#pragma unroll
+            for (int c = 0; c < KS; c++) sum += (int)((v[k][r] >> (8 * c)) & 255u) * w[r * KS + c];
+          if (f + k < f1) d[(size_t)(f + k) * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum >> kCoefBits);
+        }
       }
     };
     if (contiguous)
@@ -645,7 +643,7 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
     else
       frames(std::false_type{});
   } else {
-    for (int f = f0; f < f1; f++) {
+    for (int f = f0 + part; f < f1; f += nparts) {
       const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
       d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)v;
     }
@@ -668,21 +666,27 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
   // hipcc copy the whole argument block to scratch
   TiledPlane pl = a.plane[0];
   if (id < a.direct_blocks) {
-    // direct tiles: XCD x (= id % 8) serves pole (x & 1) of plane (x >> 1) -- the tiles around one pole read the same
-    // few source rows, which then come from HBM once and from that XCD's L2 for every other tile
-    const int xcd = id & 7, k = id >> 3;
-    const int t_local = k / a.groups;
-    g = k - t_local * a.groups;
-    const int plane = xcd >> 1, pole = xcd & 1;
-    if (plane >= a.nplanes || T360_DBG(a, 2)) return;
-    if (plane == 1) pl = a.plane[1];
-    if (plane == 2) pl = a.plane[2];
-    if (plane == 3) pl = a.plane[3];
-    const int count = pole ? pl.ndirect - pl.ndirect_top : pl.ndirect_top;
-    if (t_local >= count) return;
-    b = pole ? pl.ndirect_top + t_local : t_local;
+    // direct tiles, one work item per (tile, frame group); consecutive ids run on different XCDs, so the pole tiles --
+    // every lane of which pulls whole 128-byte lines of the polar source rows through its XCD's L2 for 4 bytes each --
+    // are spread over all eight L2s (concentrated on one XCD per pole they slowed that XCD's staged tiles enough to
+    // set the launch's critical path)
+    int t_idx = id / a.groups;
+    g = id - t_idx * a.groups;
+    if (t_idx >= a.total_direct || T360_DBG(a, 2)) return;
+    if (a.nplanes > 1 && t_idx >= pl.ndirect) {
+      t_idx -= pl.ndirect;
+      pl = a.plane[1];
+      if (a.nplanes > 2 && t_idx >= pl.ndirect) {
+        t_idx -= pl.ndirect;
+        pl = a.plane[2];
+        if (a.nplanes > 3 && t_idx >= pl.ndirect) {
+          t_idx -= pl.ndirect;
+          pl = a.plane[3];
+        }
+      }
+    }
     f0 = g * a.frames_per_block;
-    direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + b], f0, min(f0 + a.frames_per_block, a.nframes));
+    direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + t_idx], f0, min(f0 + a.frames_per_block, a.nframes));
     return;
   }
   {

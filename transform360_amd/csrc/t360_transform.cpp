@@ -1022,10 +1022,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.tail_frames = std::max(1, std::min(fused.frames_per_block, tail_frames_));
     fused.tail_groups = (n_frames + fused.tail_frames - 1) / fused.tail_frames;
     fused.tail_percent = fused.tail_groups > fused.groups ? tail_percent_ : 0;
-    int max_pole = 0;
-    for (int k = 0; k < fused.nplanes; k++)
-      max_pole = std::max(max_pole, std::max(fused.plane[k].ndirect_top, fused.plane[k].ndirect - fused.plane[k].ndirect_top));
-    fused.direct_blocks = 8 * max_pole * fused.groups;
+    fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
 #ifdef T360_INSTRUMENT
     t360::DeviceBuffer trace;
     const char* trace_path = getenv("T360_TRACE");
