@@ -31,3 +31,22 @@ extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, 
   for (int i = 0; i < 33; i++) stats[12 + i] = s.pieces_hist[i];
   return 1;
 }
+
+// the staged tiles of the plan in execution order: out[4*i] = kind, pieces, ox, oy (returns the tile count, <= cap)
+extern "C" int t360_plan_tiles(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces, int waves,
+                               int* out, int cap) {
+  t360::PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces;
+  o.waves = waves;
+  t360::HostGatherPlan plan;
+  if (!t360::plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
+  int n = 0;
+  for (int i = 0; i < plan.ntiles && n < cap; i++, n++) {
+    out[4 * n] = plan.tiles[i].kind;
+    out[4 * n + 1] = plan.tiles[i].pieces;
+    out[4 * n + 2] = plan.tiles[i].ox;
+    out[4 * n + 3] = plan.tiles[i].oy;
+  }
+  return n;
+}
