@@ -4,32 +4,31 @@
 // SURVEY.md Appendix A.3/A.4); written around the bicubic 4x4 stencil and instantiated for nearest,
 // bilinear and Lanczos4 as well.  Organised for MI355X:
 //
-//   * one workgroup (4 waves) owns one OUTPUT tile (64x16, 32x32 or 128x8 px with
-//     4 px per lane, lane = column; 16x16 px with 1 px per lane near the poles; the plan's choice,
-//     t360_plan.cpp) and walks `frames_per_block` frames of the batch with it.  Everything that depends only
-//     on geometry -- the LDS address of each stencil row of each pixel, the 16 Q15 weights per pixel, the
-//     source addresses of the chunks it stages -- is set up ONCE per tile and kept in registers for all
-//     frames: per frame a lane only moves bytes and issues dot products.
+//   * one workgroup (8 waves; 4 for Lanczos4) owns one OUTPUT tile (128x16 px on 512 lanes, 4 px per lane, lane =
+//     column; 64x16 / 32x32 px on 256 lanes where that does not fit the staging budget; 16x16 px with 1 px per lane
+//     near the poles; the plan's choice, t360_plan.cpp) and walks `frames_per_block` frames of the batch with it.
+//     Everything that depends only on geometry -- the LDS address of each stencil row of each pixel, the 16 Q15
+//     weights per pixel, the source addresses of the chunks it stages -- is set up ONCE per tile and kept in
+//     registers for all frames: per frame a lane only moves bytes and issues dot products.
 //   * per frame the tile's source FOOTPRINT (exactly the 16-byte chunks its stencils touch, packed row after
-//     row; planned at init) goes global -> LDS by DMA (global_load_lds_dwordx4, no VGPR round trip) into a
-//     ring of K slots, K-1 frames ahead of the frame being computed; completion is tracked with counted
+//     row with a bank-aware placement; planned at init) goes global -> LDS by DMA (global_load_lds_dwordx4, no VGPR
+//     round trip) into a ring of K <= 3 slots, K-1 frames ahead of the frame being computed.  Every wave moves its
+//     share of the chunks and gathers its share of the pixels; completion is tracked with counted
 //     s_waitcnt vmcnt(N) and ONE workgroup barrier per frame.  The +-180 degree seam and BORDER_WRAP across
 //     the poles are resolved in the chunk addresses, so the gather itself never wraps.
-//   * every chunk is written to LDS TWICE: copy A at its natural position, copy B four bytes further (LDS-DMA
-//     accepts any dword-aligned destination).  A 4-byte stencil-row window at byte offset o then lies inside
-//     ONE 8-byte aligned qword of copy A (o % 8 < 4) or copy B (o % 8 >= 4) and is fetched with ds_read_b64,
-//     which costs half the LDS cycles of the two aligned dwords (ds_read2_b32) a single copy needs
-//     (MI355X_MICROARCH.md "LDS"; tools/ubench/lds_patterns.hip).  The second write is an L1 hit.
+//   * a 4-byte stencil-row window is read as the two aligned dwords that hold it (+ v_alignbit).  T360_DUAL=1 keeps
+//     the variant that writes every chunk twice (copy B four bytes further) and reads ONE ds_read_b64 per window:
+//     half the LDS cycles, but twice the LDS per frame in flight, and the kernel waits for memory, not for LDS.
+//     (gfx950 serves unaligned ds_read_b32 correctly but at 26 cycles: tools/ubench/lds_unaligned.hip.)
 //   * ring slots come in a few compile-time sizes (the tile picks the smallest that holds it) and the frame loop
-//     is unrolled over the slots, so the slot base is an immediate of the ds_read: no per-frame address
-//     arithmetic at all, and small tiles keep more frames in flight than large ones.
-//   * the 4x4 stencil of one output pixel costs 4 ds_read_b64 + 4 v_alignbit and 8 v_dot4: weights are split
-//     into a signed high byte and an unsigned low byte (w = 256*wh + wl) and pixels enter the high part as
+//     is unrolled over the slots, so slot addresses are constants of the unrolled code.
+//   * the 4x4 stencil of one output pixel costs 8 LDS dwords + 4 v_alignbit + 4 v_xor and 8 v_dot4: weights are
+//     split into a signed high byte and an unsigned low byte (w = 256*wh + wl) and pixels enter the high part as
 //     p-128,   SUM p*w = 256 * (SUM (p-128)*wh + 128 * SUM wh) + SUM p*wl,
 //     all exact in int32, so results are bit-identical to the integer formulation.
 //   * all planes of the frame (Y, U, V) are tiles of ONE launch, including the few tiles around the poles
-//     that are gathered straight from global memory; workgroups are numbered so that every XCD gets a
-//     contiguous range of the execution-ordered tile list (shared halo -> shared L2).
+//     that are gathered straight from global memory (dealt to all eight XCDs); staged workgroups are numbered so
+//     that every XCD gets a contiguous range of the execution-ordered (Z-order) tile list: shared halo -> shared L2.
 //   * no MFMA: this is a gather, not a contraction.
 #include <hip/hip_runtime.h>
 
