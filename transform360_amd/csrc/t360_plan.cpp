@@ -7,7 +7,7 @@
 //     would stage up to 2.6x the bytes that are used, so the footprint is kept exact, row by row;
 //   * an LDS placement: the box rows are packed back to back (row r holds the chunks first[r] .. last[r] of its
 //     source row at LDS chunk positions pos[r] ..), so LDS and DMA lanes carry almost no holes either;
-//   * the chunk table the loader wave walks: per LDS position the source (row, 16-byte column), with the
+//   * the chunk table the waves walk when they stage a frame: per LDS position the source (row, 16-byte column), with the
 //     +-180 degree seam and BORDER_WRAP across the poles already resolved; positions nobody needs repeat
 //     their predecessor's source chunk (an L1 hit, no HBM traffic);
 //   * the pixel words in the lane order of the gather (box row and x of the stencil's top-left tap, phase) and the
