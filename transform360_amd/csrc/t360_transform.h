@@ -142,7 +142,9 @@ class VideoFrameTransform {
   int waves_ = 8;
   int frames_per_block_ = 64;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
-  int tail_percent_ = 25, tail_frames_ = 16;  // the last quarter of the tile list walks the batch in runs of 16 frames
+  int tail_percent_ = 12, tail_frames_ = 16;  // the last eighth of every XCD's tiles walks the batch in runs of 16 frames
+                                               // (short workgroups drain the launch; each pays the ~5 us start-up again,
+                                               // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
