@@ -197,6 +197,11 @@ int t360o_transform_pos(const FrameTransformContext* c, float x, float y, float*
   float yaw = 0, pitch = 0;
   int hasMapping = 1;
   if (c->output_layout != LAYOUT_FLAT_FIXED) y = 1.0f - y; /* :936-938 */
+  /* The reference declares p, vx, vy without initialisers (:939) and its face switches have no default (:1120-1185):
+   * for a face value outside the enum -- x == 1.0f exactly: the centre column of an LR output of odd scaled width, in
+   * the band where hFace + 3 = 6 -- it computes with whatever the stack holds; oracle/_ref built here produces
+   * values that match no rule (checked).  There is nothing to restate: this oracle uses (P0, PX, PY), the HIP map
+   * generator does the same, and tests/test_oracle_fuzz.py excludes those entries from the comparison with _ref. */
   const float *vx = PX, *vy = PY, *p = P0;
   int face = 0, vFace, hFace;
 

@@ -45,3 +45,23 @@ def test_oracle_equals_reference_build(seed, oracle_mod):
     if ok_r:
         assert np.array_equal(dr, do), "%d px differ for %r %r" % (np.count_nonzero(dr != do), ov, dims)
     r.close()
+
+
+@pytest.mark.parametrize("seed", [1318, 1487, 2961])
+def test_undefined_face_column_is_the_only_difference(seed, oracle_mod):
+    """LR output of odd scaled width: the centre column's x is exactly 1.0f in the left eye, hFace = 3, and in the band
+    where that makes face = 6 the reference computes with uninitialised vectors (VideoFrameTransform.cpp:939, no default
+    in the face switches :1120-1185).  The reference build's values there follow no rule; the oracle (and the HIP map
+    generator) use (P0, PX, PY).  Everything else of the map is bit-identical."""
+    O = oracle_mod
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    ov, dims, _, _ = draw(seed)
+    ctx = filter_defaults(**ov)
+    r, o = O.Ref(ctx), O.Oracle(ctx, threads=2)
+    assert r.generateMapForPlane(*dims, 0) and o.generateMapForPlane(*dims, 0)
+    mr, mo = r.map(0), o.map(0)
+    assert mr.shape == mo.shape and mr.shape[1] % 2 == 1
+    bad = np.argwhere((mr.view(np.uint32) != mo.view(np.uint32)).any(axis=2))
+    assert len(bad) > 0 and set(bad[:, 1]) == {(mr.shape[1] - 1) // 2}
+    r.close()

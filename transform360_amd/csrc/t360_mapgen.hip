@@ -262,7 +262,11 @@ __global__ __launch_bounds__(256) void mapgen_kernel(MapGenParams P, float2* __r
         face = hFace + (1 - vFace) * 3;
         break;
     }
-    // x == 1.0 cannot occur for pixel centres, but keep indices in range for safety
+    // A face outside the enum DOES occur: x == 1.0f exactly for the centre column of an LR output of odd (scaled)
+    // width, in the band where hFace + 3 = 6.  The reference then computes with uninitialised vectors (:939, its face
+    // switches have no default): whatever the build left on the stack -- there is nothing to match.  The oracle and
+    // this kernel use (P0, PX, PY) for such a pixel.
+    const bool face_ok = face >= 0 && face <= 5;
     face = face < 0 ? 0 : (face > 5 ? 5 : face);
 
     float qx, qy, qz;
@@ -280,9 +284,9 @@ __global__ __launch_bounds__(256) void mapgen_kernel(MapGenParams P, float2* __r
       x = (x - 0.5f) * P.expand_coef + 0.5f;  // :1115-1116
       y = (y - 0.5f) * P.expand_coef + 0.5f;
 
-      const float* p = kP[ftab[face][0]];
-      const float* vx = kAxis[ftab[face][1]];
-      const float* vy = kAxis[ftab[face][2]];
+      const float* p = kP[face_ok ? ftab[face][0] : iP0];
+      const float* vx = kAxis[face_ok ? ftab[face][1] : aPX];
+      const float* vy = kAxis[face_ok ? ftab[face][2] : aPY];
       qx = p[0] + vx[0] * x + vy[0] * y;  // :1187-1189
       qy = p[1] + vx[1] * x + vy[1] * y;
       qz = p[2] + vx[2] * x + vy[2] * y;
