@@ -13,7 +13,15 @@ from tests import test_gpu_fuzz as F  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "plane"
-fn = F.test_random_configuration_matches_oracle if mode == "plane" else F.test_random_batches_match_oracle
+fn = F.test_random_batches_match_oracle if mode == "batch" else F.test_random_configuration_matches_oracle
+if mode == "plane4":
+    # the same configurations on planes four times as wide and high (all tile shapes of the gather plans appear)
+    small = F.draw
+
+    def big(seed):
+        ov, (iw, ih, ow, oh), pin, pout = small(seed)
+        return ov, (iw * 4, ih * 4, ow * 4, oh * 4), pin, pout
+    F.draw = big
 O.build(ref=False)
 bad = 0
 for seed in range(first, first + count):
