@@ -275,6 +275,12 @@ def test_alpha_plane_quirk_matches(T, oracle_mod):
             assert np.array_equal(ddst.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n", [64, 65, 129])
+def test_batch_frame_count_boundaries(n, T, oracle_mod):
+    # batches longer than one run of frames per workgroup (64): a second, shorter run; the 16-frame runs of the last tiles
+    _batch_case(T, oracle_mod, dict(enable_low_pass_filter=0), n=n, dims=(640, 320, 384, 256), extra_pad=0, threads=8)
+
+
 def test_host_buffers_that_come_and_go():
     """Host planes are allocated, used a few times, freed, and new ones of other sizes take their addresses
     (tools/host_soak.py, in a child process: a stale pinned range -- what a cache of hipHostRegister'ed caller buffers
