@@ -81,7 +81,7 @@ typedef struct T360OFilterConfig {
 /* calculateKernel (VideoFrameTransform.cpp:78-94).  Returns malloc'd taps, *len set. */
 float* t360o_calculate_kernel(float sigma, int* len);
 /* calcualteFilteringConfig (VideoFrameTransform.cpp:367-501): appends to cfg. */
-void t360o_filter_config(const FrameTransformContext* ctx, int inW, int inH, int outW, int outH,
+int t360o_filter_config(const FrameTransformContext* ctx, int inW, int inH, int outW, int outH,
                          T360OFilterConfig* cfg);
 void t360o_filter_config_free(T360OFilterConfig* cfg);
 double t360o_effective_ratio(double angularDist, double offset); /* :168-170 */

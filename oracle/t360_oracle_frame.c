@@ -87,7 +87,11 @@ int t360o_generateMapForPlane(T360Oracle* o, int inW, int inH, int outW, int out
     /* the reference APPENDS on a repeated call (emplace_back, :237/:290-294); the duplicates
      * recompute identical output, so replacing is result-identical */
     t360o_filter_config_free(&p->segs);
-    t360o_filter_config(&o->ctx, inW, inH, sw, sh, &p->segs);
+    if (!t360o_filter_config(&o->ctx, inW, inH, sw, sh, &p->segs)) {
+      /* the reference has stored the warp map by now (:556) and fails in calcualteFilteringConfig (:571-576) */
+      printf("Could not generate map for plane %d. Error: kernel of negative length\n", mapIdx);
+      return 0;
+    }
   }
   return 1;
 }

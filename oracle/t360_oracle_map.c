@@ -451,9 +451,16 @@ int t360o_generate_map(const FrameTransformContext* c, int inW, int inH, int out
 /* VideoFrameTransform.cpp:78-94.  `kernel /= sum` is cv::Mat::operator/=(double), which OpenCV
  * implements as convertTo(kernel, -1, 1./sum): a float multiply by (float)(1.0/sum)
  * [OpenCV mat.inl.hpp + convert_scale 32f->32f, restated from memory; see DESIGN.md]. */
+/* A negative sigma (the band's angle beyond 90 degrees: planes a few rows high cut into more bands than that) makes the
+ * reference ask for a Mat of negative width: cv::Mat::zeros throws, generateMapForPlane catches and returns false
+ * (:78-81, :571-576).  Recorded here, reported by t360o_filter_config(). */
+static __thread int t_kernel_error;
 float* t360o_calculate_kernel(float sigma, int* len) {
   int boxHalfLength = (int)(sigma * 2);
-  if (boxHalfLength < 0) boxHalfLength = 0;
+  if (boxHalfLength < 0) {
+    t_kernel_error = 1;
+    boxHalfLength = 0;
+  }
   int n = boxHalfLength * 2 + 1;
   float* k = (float*)calloc((size_t)n, sizeof(float));
   float sum = 0;
@@ -607,8 +614,9 @@ static float fminf_std(float a, float b) { return (b < a) ? b : a; } /* std::min
 static float fmaxf_std(float a, float b) { return (a < b) ? b : a; } /* std::max */
 
 /* :367-501 */
-void t360o_filter_config(const FrameTransformContext* c, int inputWidth, int inputHeight,
+int t360o_filter_config(const FrameTransformContext* c, int inputWidth, int inputHeight,
                          int outputWidth, int outputHeight, T360OFilterConfig* cfg) {
+  t_kernel_error = 0;
   switch (c->input_stereo_format) {
     case STEREO_FORMAT_LR: inputWidth = (int)(inputWidth * 0.5); break;
     case STEREO_FORMAT_TB: inputHeight = (int)(inputHeight * 0.5); break;
@@ -628,7 +636,7 @@ void t360o_filter_config(const FrameTransformContext* c, int inputWidth, int inp
     case LAYOUT_BARREL:
     case LAYOUT_BARREL_SPLIT: hFov = 450.0f; vFov = 90.0f; break;
     case LAYOUT_EAC_32: hFov = 270.0f; vFov = 180.0f; break;
-    default: printf("Invalid layout type.\n"); return;
+    default: printf("Invalid layout type.\n"); return 0;
   }
   float sigmaY = 0.5f *
       fminf_std(c->max_kernel_half_height,
@@ -651,6 +659,7 @@ void t360o_filter_config(const FrameTransformContext* c, int inputWidth, int inp
                         inputWidth, inputHeight);
   }
   free(kernelY);
+  return t_kernel_error ? 0 : 1;
 }
 
 void t360o_filter_config_free(T360OFilterConfig* cfg) {

@@ -14,6 +14,16 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "plane"
 fn = F.test_random_batches_match_oracle if mode == "batch" else F.test_random_configuration_matches_oracle
+if mode == "tiny":
+    # the same configurations on very small planes (1 .. 40 px a side, any alignment)
+    small = F.draw
+
+    def tiny(seed):
+        import numpy as np
+        ov, _, pin, pout = small(seed)
+        r = np.random.default_rng(seed ^ 0x5EED)
+        return ov, (int(r.integers(1, 41)), int(r.integers(1, 41)), int(r.integers(1, 41)), int(r.integers(1, 41))), pin, pout
+    F.draw = tiny
 if mode == "plane4":
     # the same configurations on planes four times as wide and high (all tile shapes of the gather plans appear)
     small = F.draw

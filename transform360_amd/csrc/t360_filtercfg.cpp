@@ -30,9 +30,13 @@ const double kFov = 0.5333 * M_PI;            // :35
 
 // calculateKernel (:78-94).  `kernel /= sum` on a CV_32F cv::Mat is
 // convertTo(kernel, -1, 1./sum): every tap is multiplied by float(1.0 / sum).
+// A negative sigma (a band whose angle lies beyond 90 degrees: planes a few rows high cut into more bands than that)
+// asks the reference for a cv::Mat of negative width: Mat::zeros throws, generateMapForPlane catches and returns
+// false (:78-81, :571-576).  Same outcome here.
+struct NegativeKernel {};
 std::vector<float> gaussian_taps(float sigma) {
   int half = (int)(sigma * 2);
-  if (half < 0) half = 0;
+  if (half < 0) throw NegativeKernel{};
   std::vector<float> k((size_t)half * 2 + 1);
   float sum = 0;
   const float comp = std::fabs(sigma) < kEps ? 0.0f : (float)(0.5 / (sigma * sigma));
@@ -161,8 +165,21 @@ struct Builder {
 
 }  // namespace
 
+static bool build_filter_config_or_throw(const FrameTransformContext& c, int inputWidth, int inputHeight, int outputWidth,
+                                         int outputHeight, FilterConfig* cfg);
+
 bool build_filter_config(const FrameTransformContext& c, int inputWidth, int inputHeight,
                          int outputWidth, int outputHeight, FilterConfig* cfg) {
+  try {
+    return build_filter_config_or_throw(c, inputWidth, inputHeight, outputWidth, outputHeight, cfg);
+  } catch (const NegativeKernel&) {
+    printf("Could not generate the low-pass configuration. Error: kernel of negative length\n");
+    return false;
+  }
+}
+
+static bool build_filter_config_or_throw(const FrameTransformContext& c, int inputWidth, int inputHeight, int outputWidth,
+                                         int outputHeight, FilterConfig* cfg) {
   cfg->segments.clear();
   // one eye only; the frame path applies it to both (:373-401)
   if (c.input_stereo_format == STEREO_FORMAT_LR) inputWidth = (int)(inputWidth * 0.5);
@@ -190,7 +207,9 @@ bool build_filter_config(const FrameTransformContext& c, int inputWidth, int inp
   const float sigmaY = 0.5f * std::min(c.max_kernel_half_height, std::max(c.min_kernel_half_height, density));
   const std::vector<float> kernelY = gaussian_taps(sigmaY);
   const int bandH = (int)std::ceil(1.0 * inputHeight / c.num_vertical_segments);  // :460
-  if (bandH <= 0) return false;
+  // bandH == 0 only for an eye of height 0 (a TB frame one row high): the reference's loops then simply do not run
+  // (:318-364); with any real height ceil() gives >= 1
+  if (bandH <= 0 && inputHeight > 0) return false;
 
   Builder b{c, *cfg, inputWidth, inputHeight};
   if (c.num_vertical_segments % 2 == 0) {  // :462-473
