@@ -312,11 +312,18 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
 
   MapGenParams P;
   memset(&P, 0, sizeof(P));
+  const double mw = (double)ctx_.width_scale_factor * outputWidth + 0.5, mh = (double)ctx_.height_scale_factor * outputHeight + 0.5;
+  if (!(mw >= 1.0 && mh >= 1.0 && mw < 32768.0 && mh < 32768.0)) {  // also false for NaN / infinite factors
+    printf("Could not generate map for plane %d. Error: warp map size outside 1 .. 32767\n", idx);
+    return false;
+  }
   P.map_w = (int)(ctx_.width_scale_factor * outputWidth + 0.5);    // :524
   P.map_h = (int)(ctx_.height_scale_factor * outputHeight + 0.5);  // :525-526
   if (P.map_w <= 0 || P.map_h <= 0) return false;
-  if (P.map_w > 32767 || P.map_h > 32767) {
-    printf("Could not generate map for plane %d. Error: output plane larger than 32767\n", idx);
+  if ((int64_t)P.map_w * P.map_h > ((int64_t)1 << 28)) {
+    // 16K x 16K: the map, its sample LUT and the host copy the planner works on are 6 GB together at this size; the
+    // reference would try (and die of) an allocation of any size
+    printf("Could not generate map for plane %d. Error: warp map larger than 2^28 entries\n", idx);
     return false;
   }
   P.in_w = inputWidth;
