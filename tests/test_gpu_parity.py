@@ -80,6 +80,17 @@ def test_unsupported_request_is_refused_not_faked(T):
     from transform360_amd.abi import LAYOUT_N
     with T.VideoFrameTransform(filter_defaults(output_layout=LAYOUT_N)) as t:
         assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
+    # scale factors that overflow or are not numbers, and maps beyond 2^28 entries, are refused before anything is allocated
+    for ov in (dict(width_scale_factor=float("nan")), dict(height_scale_factor=float("inf")), dict(width_scale_factor=1e9),
+               dict(width_scale_factor=-1.0), dict(height_scale_factor=0.0)):
+        with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0, **ov)) as t:
+            assert not t.generateMapForPlane(1024, 512, 384, 256, 0)
+    with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
+        assert not t.generateMapForPlane(1024, 512, 20000, 20000, 0)
+        assert not t.generateMapForPlane(1024, 512, 384, 256, -1)
+        assert not t.generateMapForPlane(1024, 512, 384, 256, 1000)
+        assert not t.generateMapForPlane(0, 512, 384, 256, 0)
+        assert not t.generateMapForPlane(1024, 512, 384, -3, 0)
 
 
 def test_output_size_given_at_call_time_is_resized_like_the_reference(T, oracle_mod):
