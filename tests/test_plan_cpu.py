@@ -1,0 +1,64 @@
+"""CPU check of the gather planner (transform360_amd/csrc/t360_plan.cpp is pure host code): tools/plan_sim builds it
+with g++ and EMULATES the gather through the plan -- every tile's chunk table is staged into a fake LDS, every pixel's
+stencil rows are looked up the way the kernel does (pixel word -> row table -> LDS address) and the bytes found there are
+compared with the source sampled directly from the LUT; every output pixel must be covered exactly once.  The LUT is the
+oracle's map quantised the way cv::remap does."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "plan_sim"))
+
+from transform360_amd.abi import (CUBIC, LANCZOS4, LAYOUT_CUBEMAP_23_OFFCENTER, LAYOUT_EAC_32, LINEAR, NEAREST,  # noqa: E402
+                                  STEREO_FORMAT_TB, filter_defaults)
+
+CASES = {
+    "cube_bicubic": (dict(interpolation_alg=CUBIC), (640, 320, 384, 256)),
+    "cube_nearest": (dict(interpolation_alg=NEAREST), (640, 320, 384, 256)),
+    "cube_bilinear_rotated": (dict(interpolation_alg=LINEAR, fixed_yaw=33.0, fixed_pitch=-21.0, fixed_roll=9.0), (512, 256, 288, 192)),
+    "cube_lanczos": (dict(interpolation_alg=LANCZOS4), (512, 256, 192, 128)),
+    "cube23_offcentre": (dict(interpolation_alg=CUBIC, output_layout=LAYOUT_CUBEMAP_23_OFFCENTER, fixed_cube_offcenter_z=0.4),
+                         (640, 320, 256, 384)),
+    "eac_tb": (dict(interpolation_alg=CUBIC, output_layout=LAYOUT_EAC_32, input_stereo_format=STEREO_FORMAT_TB,
+                    output_stereo_format=STEREO_FORMAT_TB), (512, 512, 288, 384)),
+    "ragged_output": (dict(interpolation_alg=CUBIC), (640, 320, 300, 200)),
+    "config2_luma": (dict(interpolation_alg=CUBIC), (3840, 1920, 1536, 1024)),     # BASELINE config 2, both plane shapes
+    "config2_chroma": (dict(interpolation_alg=CUBIC), (1920, 960, 768, 512)),
+}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    import plan_sim
+    L = plan_sim.build()
+    L.t360_plan_verify.restype = C.c_longlong
+    L.t360_plan_verify.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("waves,pieces", [(8, 24), (4, 16)])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gather_through_the_plan_reads_the_right_bytes(name, waves, pieces, sim, oracle_mod):
+    O = oracle_mod
+    ov, (in_w, in_h, out_w, out_h) = CASES[name]
+    ctx = filter_defaults(enable_low_pass_filter=0, **ov)
+    o = O.Oracle(ctx, threads=4)
+    assert o.generateMapForPlane(in_w, in_h, out_w, out_h, 0)
+    q, nn = O.quantize_map(o.map(0))
+    ks = {NEAREST: 1, LINEAR: 2, CUBIC: 4, LANCZOS4: 8}[int(ctx.interpolation_alg)]
+    lut = np.zeros(q.shape[:2] + (4,), np.int16)
+    if ks == 1:
+        lut[..., 0], lut[..., 1] = np.clip(nn[..., 0], -32768, 32767), np.clip(nn[..., 1], -32768, 32767)
+    else:
+        lut[..., 0], lut[..., 1] = np.clip(q[..., 0], -32768, 32767), np.clip(q[..., 1], -32768, 32767)
+        lut[..., 2] = q[..., 2].astype(np.int16)
+    lut = np.ascontiguousarray(lut)
+    src = np.random.default_rng(3).integers(0, 256, (in_h, in_w), dtype=np.uint8)
+    if ks == 8:
+        waves, pieces = 4, min(pieces, 16)   # Lanczos4 plans: workgroups of 4 waves, 16x16 tiles
+    bad = sim.t360_plan_verify(lut.ctypes.data, out_w, out_h, in_w, in_h, ks, pieces, waves, src.ctypes.data)
+    assert bad == 0

@@ -50,3 +50,100 @@ extern "C" int t360_plan_tiles(const t360::LutEntry* lut, int dw, int dh, int sw
   }
   return n;
 }
+
+// CPU emulation of the gather THROUGH the plan: stage every tile's chunk table into a fake LDS, look every pixel's
+// stencil rows up the way the kernel does (pixel word -> row table -> LDS address) and compare the bytes with the
+// source sampled directly from the LUT (BORDER_WRAP on both axes).  Also: every output pixel is covered exactly once.
+// Returns the number of violations (0 = the plan is sound); prints the first few.
+extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces, int waves,
+                                      const unsigned char* src /* sw x sh, stride sw */) {
+  using namespace t360;
+  PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces;
+  o.waves = waves;
+  HostGatherPlan plan;
+  if (!plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
+  auto wrapi = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
+  const int lo = ks == 1 ? 0 : ks / 2 - 1;
+  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  const size_t wstride = (size_t)tile_words(ks, waves);
+  const int per_lane = ks == 8 ? 1 : 4;
+  std::vector<unsigned char> cover((size_t)dw * dh, 0);
+  std::vector<unsigned char> lds;
+  long long bad = 0;
+  auto complain = [&](const char* what, int tile, int px, int py) {
+    if (bad++ < 8) printf("plan_verify: %s (tile %d, output pixel %d,%d)\n", what, tile, px, py);
+  };
+  for (int ti = 0; ti < plan.ntiles; ti++) {
+    const TileDesc& t = plan.tiles[(size_t)ti];
+    const uint32_t* tc = &plan.chunks[(size_t)ti * cstride];
+    const uint32_t* words = &plan.tlut[(size_t)ti * wstride];
+    if (t.pieces <= 0 || t.pieces > max_pieces) complain("piece count outside the budget", ti, t.ox, t.oy);
+    lds.assign((size_t)t.pieces * 1024, 0);
+    for (int pos = 0; pos < t.pieces * kPieceChunks; pos++) {
+      const uint32_t e = tc[pos];
+      const int sy = (int)(e >> 12), cx = (int)(e & 4095u);
+      if (sy >= sh || (cx + 1) * kStageChunk > sw) {
+        complain("chunk entry outside the source plane", ti, t.ox, t.oy);
+        continue;
+      }
+      memcpy(&lds[(size_t)pos * kStageChunk], src + (size_t)sy * sw + (size_t)cx * kStageChunk, kStageChunk);
+    }
+    auto row_base = [&](int r) { return (int)(int16_t)(tc[cstride - 64 + (size_t)(r >> 1)] >> (16 * (r & 1))); };
+    int w = 0, h = 0, lanes = 256, npx = 4;
+    switch (t.kind) {
+      case kTileStaged32: w = 32; h = 32; break;
+      case kTileStaged16: w = 16; h = 16; npx = 1; break;
+      case kTileStrip128: w = 128; h = 8; break;
+      case kTileWide64: w = 64; h = 16; break;
+      case kTileWide128: w = 128; h = 16; lanes = 512; break;
+      default: complain("unknown tile kind", ti, t.ox, t.oy); continue;
+    }
+    for (int tid = 0; tid < lanes; tid++)
+      for (int p = 0; p < npx; p++) {
+        int px, py;
+        if (npx == 4) {
+          px = t.ox + tid % w;
+          py = t.oy + (tid / w) * 4 + p;
+        } else {
+          px = t.ox + (tid & 15);
+          py = t.oy + (tid >> 4);
+        }
+        const uint32_t word = words[(size_t)tid * per_lane + p];
+        const bool inside = px < dw && py < dh && py < t.oy + h;
+        if (!inside) {
+          if (!(word >> 31)) complain("live pixel word outside the plane", ti, px, py);
+          continue;
+        }
+        if (word >> 31) {
+          complain("dead pixel word inside the plane", ti, px, py);
+          continue;
+        }
+        cover[(size_t)py * dw + px]++;
+        const LutEntry& e = lut[(size_t)py * dw + px];
+        const int x = (int)(word & 2047u), row = (int)((word >> kWordRowShift) & 255u), frac = (int)((word >> kWordFracShift) & 1023u);
+        if (ks != 1 && frac != (int)e.frac) complain("phase differs from the LUT", ti, px, py);
+        for (int k = 0; k < ks; k++) {
+          const int off = row_base(row + k) * kStageChunk + x;
+          for (int c = 0; c < ks; c++) {
+            const unsigned char want = src[(size_t)wrapi((int)e.iy - lo + k, sh) * sw + (size_t)wrapi((int)e.ix - lo + c, sw)];
+            if (off + c < 0 || (size_t)(off + c) >= lds.size() || lds[(size_t)(off + c)] != want) {
+              complain("staged byte differs from the source tap", ti, px, py);
+              k = ks;
+              break;
+            }
+          }
+        }
+      }
+  }
+  for (int i = 0; i < plan.ndirect; i++) {
+    const TileDesc& t = plan.tiles[(size_t)plan.ntiles + (size_t)i];
+    for (int y = t.oy; y < t.oy + 16 && y < dh; y++)
+      for (int x = t.ox; x < t.ox + 16 && x < dw; x++) cover[(size_t)y * dw + x]++;
+  }
+  for (int y = 0; y < dh; y++)
+    for (int x = 0; x < dw; x++)
+      if (cover[(size_t)y * dw + x] != 1) complain("output pixel not covered exactly once", -1, x, y);
+  return bad;
+}
