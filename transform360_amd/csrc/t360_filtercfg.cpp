@@ -165,6 +165,22 @@ struct Builder {
 
 }  // namespace
 
+int pack_shifted_taps(const std::vector<int>& kx_q8, std::vector<uint32_t>* out) {
+  const int kx = (int)kx_q8.size(), rx = kx / 2, m = (4 - rx % 4) % 4;
+  const int nd = (kx + m + 3 + 3) / 4;
+  if (kx <= 0 || nd > kWideMaxNd) return 0;
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < kWideTapStride; i++) {
+      uint32_t w = 0;
+      for (int b = 0; b < 4; b++) {
+        const int k = 4 * i + b - (m + j);
+        if (k >= 0 && k < kx) w |= (uint32_t)kx_q8[(size_t)k] << (8 * b);
+      }
+      out->push_back(w);
+    }
+  return nd;
+}
+
 static bool build_filter_config_or_throw(const FrameTransformContext& c, int inputWidth, int inputHeight, int outputWidth,
                                          int outputHeight, FilterConfig* cfg);
 

@@ -2,6 +2,8 @@
 #pragma once
 
 #include <algorithm>
+#include <stdint.h>
+
 #include <vector>
 
 #include "t360_internal.h"
@@ -20,6 +22,12 @@ struct Segment {
 struct FilterConfig {
   std::vector<Segment> segments;
 };
+
+// Shifted tap variants of the wide low-pass path (t360_lowpass.hip): the row pass of output pixel px0 + j (px0 % 4 == 0,
+// j = 0..3) is a dot product of the ALIGNED source dwords from byte (px0 - rx - m) on, rx = taps / 2, m = (-rx) & 3,
+// with the taps shifted by m + j bytes.  Appends 4 x kWideTapStride dwords (variant j at [j * kWideTapStride]) to `out`
+// and returns the number of dwords a variant can be non-zero in, or 0 (nothing appended) when that exceeds kWideMaxNd.
+int pack_shifted_taps(const std::vector<int>& kx_q8, std::vector<uint32_t>* out);
 
 // Reference calcualteFilteringConfig (VideoFrameTransform.cpp:367-501) for one plane shape.
 // inputWidth/Height: plane size; outputWidth/Height: the SCALED output size (:560-565).

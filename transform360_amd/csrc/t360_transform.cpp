@@ -503,23 +503,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
       // ALIGNED source dwords from (px0 - rx - m) on, m = (-rx) & 3, with the taps shifted by m + j bytes -- four
       // variants of the packed taps instead of a realignment of the pixels per output pixel
       d.kxs_off = (int)sh.size();
-      d.kxs_nd = 0;
-      if (fast) {
-        const int kx = (int)s.kx_q8.size(), rx = kx / 2, m = (4 - rx % 4) % 4;
-        const int nd = (kx + m + 3 + 3) / 4;
-        if (nd <= kWideMaxNd) {
-          d.kxs_nd = nd;
-          for (int j = 0; j < 4; j++)
-            for (int i = 0; i < kWideTapStride; i++) {
-              uint32_t w = 0;
-              for (int b = 0; b < 4; b++) {
-                const int k = 4 * i + b - (m + j);
-                if (k >= 0 && k < kx) w |= (uint32_t)s.kx_q8[(size_t)k] << (8 * b);
-              }
-              sh.push_back(w);
-            }
-        }
-      }
+      d.kxs_nd = fast ? pack_shifted_taps(s.kx_q8, &sh) : 0;
       p.seg_fast.push_back(fast ? (d.kxs_nd ? 2 : 1) : 0);
       d.left = s.left;
       d.top = s.top;
