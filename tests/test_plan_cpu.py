@@ -62,3 +62,25 @@ def test_gather_through_the_plan_reads_the_right_bytes(name, waves, pieces, sim,
         waves, pieces = 4, min(pieces, 16)   # Lanczos4 plans: workgroups of 4 waves, 16x16 tiles
     bad = sim.t360_plan_verify(lut.ctypes.data, out_w, out_h, in_w, in_h, ks, pieces, waves, src.ctypes.data)
     assert bad == 0
+
+
+@pytest.mark.parametrize("interp,ks", [(LINEAR, 2), (CUBIC, 4), (LANCZOS4, 8)])
+def test_packed_weights_reproduce_the_q15_table(interp, ks, sim, oracle_mod):
+    """pack_weights(): w = 256 * (signed high byte) + (unsigned low byte), window (r, q) = taps 4q..4q+3 of stencil row r,
+    and 128 * SUM(high) behind the 2 * nw weight dwords -- for every phase of OpenCV's table."""
+    tab = oracle_mod.inter_tab(interp).astype(np.int16)           # [1024, ks * ks]
+    stride = {2: 8, 4: 12, 8: 36}[ks]
+    out = np.zeros(1024 * stride, np.uint32)
+    sim.t360_pack_weights.restype = C.c_int
+    sim.t360_pack_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    assert sim.t360_pack_weights(np.ascontiguousarray(tab).ctypes.data, ks, out.ctypes.data) == out.size
+    win = 2 if ks == 8 else 1
+    nw = ks * win
+    o = out.reshape(1024, stride)
+    hi = o[:, :nw].copy().view(np.int8).reshape(1024, nw, 4).astype(np.int64)
+    lo = o[:, nw:2 * nw].copy().view(np.uint8).reshape(1024, nw, 4).astype(np.int64)
+    w = (256 * hi + lo).reshape(1024, ks, win * 4)[:, :, :ks].reshape(1024, ks * ks)
+    assert np.array_equal(w, tab.astype(np.int64))
+    unused = (256 * hi + lo).reshape(1024, ks, win * 4)[:, :, ks:]
+    assert not unused.any()                                        # bilinear: bytes 2-3 of its window
+    assert np.array_equal(o[:, 2 * nw].view(np.int32).astype(np.int64), 128 * hi.sum(axis=(1, 2)))

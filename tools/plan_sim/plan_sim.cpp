@@ -147,3 +147,12 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
       if (cover[(size_t)y * dw + x] != 1) complain("output pixel not covered exactly once", -1, x, y);
   return bad;
 }
+
+// pack_weights() of the planner for a Q15 table of phases x ks x ks shorts; out must hold phases * pack_dwords(ks) dwords
+extern "C" int t360_pack_weights(const short* tab, int ks, unsigned* out) {
+  std::vector<int16_t> t(tab, tab + (size_t)t360::kInterTabSize * t360::kInterTabSize * ks * ks);
+  std::vector<uint32_t> v;
+  t360::pack_weights(t, ks, &v);
+  memcpy(out, v.data(), v.size() * sizeof(uint32_t));
+  return (int)v.size();
+}
