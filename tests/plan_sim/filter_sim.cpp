@@ -1,4 +1,4 @@
-// tools/plan_sim/filter_sim.cpp -- the library's HOST-side low-pass configuration (transform360_amd/csrc/
+// tests/plan_sim/filter_sim.cpp -- the library's HOST-side low-pass configuration (transform360_amd/csrc/
 // t360_filtercfg.cpp: segments, Gaussian taps, Q8 taps, the shifted tap variants of the wide path) built for the host,
 // so that tests/test_filtercfg_cpu.py can compare it with the oracle without a GPU.  Development / test tool.
 #include <cstring>

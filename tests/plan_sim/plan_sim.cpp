@@ -1,6 +1,6 @@
-// tools/plan_sim/plan_sim.cpp -- the product's gather planner (transform360_amd/csrc/t360_plan.cpp) built
+// tests/plan_sim/plan_sim.cpp -- the product's gather planner (transform360_amd/csrc/t360_plan.cpp) built
 // for the host, so that tile shapes, fetched bytes and modelled LDS bank conflicts can be compared offline
-// (tools/plan_sim/plan_sim.py feeds it the oracle's LUT).  Development tool, not part of the library.
+// (tests/plan_sim/plan_sim.py feeds it the oracle's LUT).  Development tool, not part of the library.
 #include <cstdio>
 #include <cstring>
 

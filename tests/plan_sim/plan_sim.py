@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/plan_sim/plan_sim.py -- run the product's gather planner on the CPU (no GPU needed) and print what it
+"""tests/plan_sim/plan_sim.py -- run the product's gather planner on the CPU (no GPU needed) and print what it
 would stage: tiles per shape, fetched bytes per plane (vs the source plane = over-fetch before any L2 reuse),
 LDS bytes, pitch histogram and the modelled ds_read_b64 bank-conflict cycles.
 
-    python tools/plan_sim/plan_sim.py [--config 2] [--plane 0|1] [--pieces 12] [--wide 200] [--strip 0] ...
+    python tests/plan_sim/plan_sim.py [--config 2] [--plane 0|1] [--pieces 12] [--wide 200] [--strip 0] ...
 The LUT comes from the CPU oracle's map (test infrastructure) quantised the way cv::remap does.
 """
 import argparse

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""tools/fuzz_soak.py [first_seed] [count] [plane|batch] -- the random configurations of tests/test_gpu_fuzz.py (single
+"""tests/soak/fuzz_soak.py [first_seed] [count] [plane|batch] -- the random configurations of tests/test_gpu_fuzz.py (single
 planes, or yuv420p batches) for seeds beyond the ones the suite pins (development soak; prints every mismatch, exits 1
 if there was one)."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import t360_oracle as O  # noqa: E402
 from tests import test_gpu_fuzz as F  # noqa: E402

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/host_soak.py [iterations] -- host-pointer calls on buffers that come and go: arrays are allocated, used two or
+"""tests/soak/host_soak.py [iterations] -- host-pointer calls on buffers that come and go: arrays are allocated, used two or
 three times (the library pins a buffer on its second sighting), freed, and new ones of other sizes take their addresses.
 Every output is compared with the oracle: a stale pinned range would show up as wrong pixels (development soak)."""
 import os
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import t360_oracle as O  # noqa: E402
 from transform360_amd import handler as T  # noqa: E402

@@ -1,5 +1,5 @@
 """CPU check of the library's HOST-side low-pass configuration (transform360_amd/csrc/t360_filtercfg.cpp is pure host
-code; tools/plan_sim/filter_sim.cpp builds it with g++): segments, kernels and return values against the oracle for
+code; tests/plan_sim/filter_sim.cpp builds it with g++): segments, kernels and return values against the oracle for
 configurations drawn from the whole space, and the shifted tap variants of the wide low-pass kernel against a direct
 convolution."""
 import ctypes as C
@@ -13,7 +13,7 @@ from tests.test_gpu_fuzz import draw
 from transform360_amd.abi import FrameTransformContext, filter_defaults
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIM = os.path.join(ROOT, "tools", "plan_sim")
+SIM = os.path.join(ROOT, "tests", "plan_sim")
 
 
 @pytest.fixture(scope="module")

@@ -60,7 +60,7 @@ def draw(seed):
     return ov, (in_w, in_h, out_w, out_h), pin, pout
 
 
-# beyond the first 150: seeds an extended soak (tools/fuzz_soak.py, 2000 seeds) found -- LR outputs of odd scaled width,
+# beyond the first 150: seeds an extended soak (tests/soak/fuzz_soak.py, 2000 seeds) found -- LR outputs of odd scaled width,
 # whose centre column is the reference's uninitialised-vector case (tests/test_oracle_fuzz.py)
 @pytest.mark.parametrize("seed", list(range(150)) + [318, 487, 754, 1132, 1302, 1592, 1773, 1852, 1961, 2038])
 def test_random_configuration_matches_oracle(seed, oracle_mod):

@@ -294,12 +294,12 @@ def test_batch_frame_count_boundaries(n, T, oracle_mod):
 
 def test_host_buffers_that_come_and_go():
     """Host planes are allocated, used a few times, freed, and new ones of other sizes take their addresses
-    (tools/host_soak.py, in a child process: a stale pinned range -- what a cache of hipHostRegister'ed caller buffers
+    (tests/soak/host_soak.py, in a child process: a stale pinned range -- what a cache of hipHostRegister'ed caller buffers
     turns into -- ends in a GPU memory fault, which kills the process that triggers it)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "host_soak.py"), "150"], cwd=root, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "soak", "host_soak.py"), "150"], cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "150 host-pointer calls, 0 wrong" in r.stdout

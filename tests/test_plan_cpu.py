@@ -1,4 +1,4 @@
-"""CPU check of the gather planner (transform360_amd/csrc/t360_plan.cpp is pure host code): tools/plan_sim builds it
+"""CPU check of the gather planner (transform360_amd/csrc/t360_plan.cpp is pure host code): tests/plan_sim builds it
 with g++ and EMULATES the gather through the plan -- every tile's chunk table is staged into a fake LDS, every pixel's
 stencil rows are looked up the way the kernel does (pixel word -> row table -> LDS address) and the bytes found there are
 compared with the source sampled directly from the LUT; every output pixel must be covered exactly once.  The LUT is the
@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools", "plan_sim"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "plan_sim"))
 
 from transform360_amd.abi import (CUBIC, LANCZOS4, LAYOUT_CUBEMAP_23_OFFCENTER, LAYOUT_EAC_32, LINEAR, NEAREST,  # noqa: E402
                                   STEREO_FORMAT_TB, filter_defaults)

@@ -2,7 +2,7 @@
 // 16-byte boundary: correct? as fast?  (2) LDS read cost of the gather's access patterns for
 // ds_read2_b32 (two aligned dwords) vs ds_read_b64 (one aligned qword), measured against the bank model of
 // MI355X_MICROARCH.md "LDS" (32-lane groups; b32: bank = dword % 32, b64: bank = dword % 64; cycles of a
-// group = max over banks of distinct addresses on it).  The model is what tools/plan_sim uses to rank
+// group = max over banks of distinct addresses on it).  The model is what tests/plan_sim uses to rank
 // LDS layouts offline, so it is checked here on the real patterns.
 #include <hip/hip_runtime.h>
 

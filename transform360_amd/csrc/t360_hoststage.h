@@ -7,7 +7,7 @@
 // a pitched 2-D copy does not.  The caller's memory is NOT registered with the runtime: a cached hipHostRegister goes
 // stale when the caller frees a buffer and a later one takes its address (the driver unmaps the range from the GPU on
 // munmap and does not map the new pages again), and the next copy through it is a GPU memory fault -- found by
-// tools/host_soak.py; round 2 shipped such a cache for a few hours and gained nothing over the contiguous copy.
+// tests/soak/host_soak.py; round 2 shipped such a cache for a few hours and gained nothing over the contiguous copy.
 #pragma once
 
 #include <hip/hip_runtime.h>

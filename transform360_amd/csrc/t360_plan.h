@@ -1,7 +1,7 @@
 // t360_plan.h -- init-time planning of the LDS-tiled gather for one map (see t360_plan.cpp).
 //
 // Pure host C++ (no HIP): the planner works on a host copy of the sample LUT, so it can be unit-tested
-// and simulated on a machine without a GPU (tools/plan_sim.py).
+// and simulated on a machine without a GPU (tests/plan_sim.py).
 #pragma once
 
 #include <stdint.h>
@@ -25,8 +25,8 @@ struct PlanOptions {
                          // (1: rows packed back to back)
   bool row_search = true;  // per tile, the skew with the fewest modelled bank conflicts
   bool model_dual = false;   // bank model of ds_read_b64 on two copies instead of two ds_read_b32 on one
-  int model_b_shift = 0;     // extra byte offset of copy B in the bank model (tools/plan_sim.py)
-  bool model_stats = false;  // fill PlanStats::lds_cycles_model (tools/plan_sim.py)
+  int model_b_shift = 0;     // extra byte offset of copy B in the bank model (tests/plan_sim.py)
+  bool model_stats = false;  // fill PlanStats::lds_cycles_model (tests/plan_sim.py)
 };
 
 struct PlanStats {
