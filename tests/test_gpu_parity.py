@@ -346,7 +346,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
         dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
         _ready()
         assert t.transformFramePlane(src, dst, 0)
-        assert t.lastKernel() == "remap_tiled_kernel<4, 76, 8>"
+        assert t.lastKernel() == "remap_tiled_kernel<4, 38, 4>"  # a single frame: the short-batch plan (64 frames: <4, 76, 8>)
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)

@@ -193,6 +193,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     if (v >= 1 && v <= 4096) frames_per_block_ = v;
   }
   if (const char* e = getenv("T360_TAIL_PCT")) tail_percent_ = atoi(e);
+  if (const char* e = getenv("T360_SMALL_BATCH")) small_batch_ = atoi(e);
   if (const char* e = getenv("T360_TAIL_FRAMES")) tail_frames_ = atoi(e);
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
@@ -991,6 +992,9 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // Planes with a tile plan and 16-byte friendly buffers go into fused launches of the LDS-tiled kernel
   // (up to 4 planes each: Y, U and V of a yuv420p batch are ONE launch); everything else -- BARREL outputs
   // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
+  // which of the two plans: every plane of the call must have the one that is used
+  bool small = small_batch_ > 0 && n_frames < small_batch_ && interp != LANCZOS4 && waves_ != 4;
+  for (int k = 0; k < njobs && small; k++) small = planes_[jobs[k].idx].plan_small.valid || !planes_[jobs[k].idx].plan.valid;
   TiledArgs fused;
   auto reset_fused = [&]() {
     memset(&fused, 0, sizeof(fused));
@@ -1000,9 +1004,9 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
     fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
     // Lanczos4 plans hold 16x16 tiles only (one pixel per lane, 32 weight dwords each): workgroups of 4 waves
-    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : max_pieces_;
-    fused.ring_kb = fused.ks == 8 && waves_ == 8 ? 38 : ring_kb_;
-    fused.waves = fused.ks == 8 ? 4 : waves_;
+    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
+    fused.ring_kb = (fused.ks == 8 && waves_ == 8) || small ? 38 : ring_kb_;
+    fused.waves = fused.ks == 8 || small ? 4 : waves_;
 #ifdef T360_INSTRUMENT
     fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
 #endif
@@ -1052,7 +1056,8 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     // chunks go global -> LDS by DMA: 16-byte friendly source buffers only
     const bool vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
                         (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
-    if (p.plan.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && vec_ok) {
+    const PlaneState::GatherPlan& gp = small ? p.plan_small : p.plan;
+    if (gp.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && vec_ok) {
       TiledPlane tp;
       memset(&tp, 0, sizeof(tp));
       tp.src = s.ptr;
@@ -1065,13 +1070,13 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       tp.dw = j.out_w;
       tp.dh = j.out_h;
       tp.dstride = j.out_stride;
-      tp.tiles = p.plan.tiles.as<TileDesc>();
-      tp.tlut = p.plan.tlut.as<uint32_t>();
-      tp.chunks = p.plan.chunks.as<uint32_t>();
+      tp.tiles = gp.tiles.as<TileDesc>();
+      tp.tlut = gp.tlut.as<uint32_t>();
+      tp.chunks = gp.chunks.as<uint32_t>();
       tp.lut = p.lut.as<LutEntry>();
-      tp.ntiles = p.plan.ntiles;
-      tp.ndirect = p.plan.ndirect;
-      tp.ndirect_top = p.plan.ndirect_top;
+      tp.ntiles = gp.ntiles;
+      tp.ndirect = gp.ndirect;
+      tp.ndirect_top = gp.ndirect_top;
       tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
                         (!multi || (j.out_frame_bytes & 3) == 0);
       if (fused.nplanes == 4 && !flush_fused()) return false;
@@ -1106,6 +1111,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
 // of 16) simply have no plan and use the general gather.
 bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, int in_w, int in_h) {
   p.plan.valid = false;
+  p.plan_small.valid = false;
   const bool barrel = P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT;
   const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
   if (ks == 0 || barrel || !use_tiled_ || (in_w & 15) != 0) return true;
@@ -1114,35 +1120,46 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
   if (!check(hipMemcpyAsync(lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
       !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
     return false;
-  PlanOptions o;
-  o.ks = ks;
-  o.waves = ks == 8 ? 4 : waves_;
-  o.max_pieces = ks == 8 ? std::min(max_pieces_, 16) : max_pieces_;
-  o.wide_pct = plan_wide_pct_;
-  o.strip_pct = plan_strip_pct_;
-  o.band = plan_band_ > 0 ? plan_band_ : 4;
-  o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
-  o.row_pad = plan_row_pad_;
-  o.row_align = plan_row_align_;
-  HostGatherPlan hp;
-  if (!plan_gather(lut.data(), P.map_w, P.map_h, in_w, in_h, o, &hp)) return true;  // not plannable: general gather
-  if (!p.plan.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
-      !p.plan.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !p.plan.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
-    return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
-  if ((!hp.tiles.empty() &&
-       !check(hipMemcpyAsync(p.plan.tiles.as<void>(), hp.tiles.data(), hp.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
-                             stream_), "hipMemcpy(tiles)")) ||
-      !check(hipMemcpyAsync(p.plan.tlut.as<void>(), hp.tlut.data(), hp.tlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                            stream_), "hipMemcpy(tlut)") ||
-      !check(hipMemcpyAsync(p.plan.chunks.as<void>(), hp.chunks.data(), hp.chunks.size() * sizeof(uint32_t),
-                            hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
-      !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
-    return false;
-  p.plan.ntiles = hp.ntiles;
-  p.plan.ndirect = hp.ndirect;
-  p.plan.ndirect_top = hp.ndirect_top;
-  p.plan.stats = hp.stats;
-  p.plan.valid = true;
+  auto build = [&](PlaneState::GatherPlan& g, int waves, int max_pieces) -> bool {
+    PlanOptions o;
+    o.ks = ks;
+    o.waves = waves;
+    o.max_pieces = max_pieces;
+    o.wide_pct = plan_wide_pct_;
+    o.strip_pct = plan_strip_pct_;
+    o.band = plan_band_ > 0 ? plan_band_ : 4;
+    o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
+    o.row_pad = plan_row_pad_;
+    o.row_align = plan_row_align_;
+    HostGatherPlan hp;
+    if (!plan_gather(lut.data(), P.map_w, P.map_h, in_w, in_h, o, &hp)) return true;  // not plannable: general gather
+    if (!g.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
+        !g.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !g.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
+      return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
+    if ((!hp.tiles.empty() &&
+         !check(hipMemcpyAsync(g.tiles.as<void>(), hp.tiles.data(), hp.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
+                               stream_), "hipMemcpy(tiles)")) ||
+        !check(hipMemcpyAsync(g.tlut.as<void>(), hp.tlut.data(), hp.tlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              stream_), "hipMemcpy(tlut)") ||
+        !check(hipMemcpyAsync(g.chunks.as<void>(), hp.chunks.data(), hp.chunks.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
+        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+      return false;
+    g.ntiles = hp.ntiles;
+    g.ndirect = hp.ndirect;
+    g.ndirect_top = hp.ndirect_top;
+    g.stats = hp.stats;
+    g.waves = waves;
+    g.max_pieces = max_pieces;
+    g.valid = true;
+    return true;
+  };
+  const int waves = ks == 8 ? 4 : waves_;
+  if (!build(p.plan, waves, ks == 8 ? std::min(max_pieces_, 16) : max_pieces_)) return false;
+  // Short batches (and the per-plane calls of the reference ABI) run better on workgroups of 4 waves, four to a CU:
+  // a workgroup's start-up is then overlapped by three others instead of one (8 frames: 0.049 -> 0.043 ms, 16 frames:
+  // 0.076 -> 0.068 ms for BASELINE config 2).  Their tiles are at most 64x16, so they have their own plan.
+  if (waves != 4 && small_batch_ > 0 && !build(p.plan_small, 4, kSmallPlanPieces)) return false;
   return true;
 }
 

@@ -94,9 +94,10 @@ class VideoFrameTransform {
     struct GatherPlan {
       bool valid = false;
       int ntiles = 0, ndirect = 0, ndirect_top = 0;  // staged tiles first in `tiles`, the direct tiles behind them
+      int waves = 0, max_pieces = 0;                 // what it was planned for
       t360::DeviceBuffer tiles, tlut, chunks;
       t360::PlanStats stats;
-    } plan;
+    } plan, plan_small;  // plan_small: workgroups of 4 waves, for batches shorter than small_batch_ frames
   };
 
   bool check(hipError_t e, const char* what) const;
@@ -145,6 +146,8 @@ class VideoFrameTransform {
   int tail_percent_ = 12, tail_frames_ = 16;  // the last eighth of every XCD's tiles walks the batch in runs of 16 frames
                                                // (short workgroups drain the launch; each pays the ~5 us start-up again,
                                                // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
+  int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
+  static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
