@@ -20,6 +20,7 @@ def main():
     for v in variants:
         for k in keys:
             os.environ.pop(k, None)
+        os.environ["T360_SMALL_BATCH"] = "0"   # the 5-frame batch below must exercise the plan the variant configures
         os.environ.update(v)
         ov = dict(num_vertical_segments=5, num_horizontal_segments=4) if ("T360_NO_FAST_LOWPASS" in v or "T360_NO_WIDE_LOWPASS" in v) else dict(
             enable_low_pass_filter=0)

@@ -314,7 +314,7 @@ VARIANTS = [
     {"T360_ROW_ALIGN": "1"}, {"T360_ROW_ALIGN": "4"}, {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"},
     {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
     {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
-    {"T360_NO_WIDE_LOWPASS": "1"},
+    {"T360_NO_WIDE_LOWPASS": "1"}, {"T360_SMALL_BATCH": "1000"},
 ]
 
 
@@ -397,14 +397,16 @@ def _threads():
     return max(4, min(32, os.cpu_count() or 4))
 
 
-def test_config2_batch_full_size_all_planes(T, oracle_mod):
-    _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, enable_low_pass_filter=0), n=19,
+# Batches of 24 frames or more run the 8-wave plan (128x16 tiles, what bench.py measures), shorter ones the 4-wave plan
+@pytest.mark.parametrize("n", [27, 19])
+def test_config2_batch_full_size_all_planes(n, T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, enable_low_pass_filter=0), n=n,
                 dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
 
 
 def test_config3_batch_full_size_all_planes(T, oracle_mod):
     _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32,
-                                    adjust_kernel=1, enable_multi_threading=1), n=17,
+                                    adjust_kernel=1, enable_multi_threading=1), n=25,
                 dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
 
 
@@ -420,7 +422,7 @@ def test_config4_batch_full_size_all_planes(T, oracle_mod):
 
 
 def test_bilinear_batch_full_size_all_planes(T, oracle_mod):
-    _batch_case(T, oracle_mod, dict(interpolation_alg=LINEAR, enable_low_pass_filter=0), n=17,
+    _batch_case(T, oracle_mod, dict(interpolation_alg=LINEAR, enable_low_pass_filter=0), n=26,
                 dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
 
 
