@@ -341,11 +341,11 @@ class Planner {
       for (int r = 0; r < f.rows; r++) {
         if (f.first[(size_t)r] < 0) continue;
         const uint8_t* m = &f.mask[(size_t)r * f.ncols];
-        int prev = -(1 << 30);
+        int prev_line = -(1 << 30);
         for (int c = f.first[(size_t)r]; c <= f.last[(size_t)r]; c++)
           if (m[c]) {
             const int line = (f.c0 + c) >> 3;  // 8 chunks of 16 bytes
-            if (line != prev) lines++, prev = line;
+            if (line != prev_line) lines++, prev_line = line;
           }
       }
       st.line_bytes += lines * 128;

@@ -491,10 +491,10 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
       if (fast) {
         p.fast_ky = (int)s.ky_q8.size();
         d.kx_groups = ((int)s.kx_q8.size() + 3) / 4;
-        for (int g = 0; g < d.kx_groups; g++) {
+        for (int grp = 0; grp < d.kx_groups; grp++) {
           uint32_t w = 0;
           for (int b = 0; b < 4; b++) {
-            const size_t k = (size_t)g * 4 + b;
+            const size_t k = (size_t)grp * 4 + b;
             if (k < s.kx_q8.size()) w |= (uint32_t)s.kx_q8[k] << (8 * b);
           }
           pk.push_back(w);
