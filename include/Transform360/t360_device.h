@@ -83,10 +83,11 @@ int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i
 /* ---- what ran (benchmark reporting) ---- */
 
 /* Name of the gather kernel the most recent transform call of this handle launched, e.g.
- * "remap_tiled_kernel<4, 8, 2>" (taps per axis, staging budget in KiB per tile and copy, ring slots) or
- * "remap_gather_kernel"; "" before the first call.  The string lives as long as the handle. */
+ * "remap_tiled_kernel<4, 76, 8>" (taps per axis, KiB of LDS per workgroup, waves per workgroup; batches of fewer than 24
+ * frames and single-plane calls run "<4, 38, 4>") or "remap_gather_kernel"; "" before the first call.  The string lives
+ * as long as the handle. */
 const char* T360_lastKernel(VideoFrameTransform* transform);
-/* Gather plan of `map_index`: stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
+/* Gather plan of `map_index` (the one long batches use): stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
  * by the staged tiles, bytes of LDS filled per frame (one copy), pixels in direct tiles, bytes of the tile
  * tables on the device, 0, 0.  Returns 0 when the plane has no tile plan (it then uses the general gather). */
 int T360_getPlanStats(VideoFrameTransform* transform, int map_index, int64_t* stats8);
