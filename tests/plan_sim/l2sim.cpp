@@ -1,0 +1,265 @@
+// tests/plan_sim/l2sim.cpp -- offline model of the fabric reads of the tiled gather (development tool).
+//
+// Replays the launch the kernel would make for a yuv420p batch: every XCD owns a contiguous range of the
+// execution-ordered tile list (Y tiles, then U, then V), `slots` workgroups are resident per XCD, each walks `nframes`
+// frames with its tile, one frame per tick, and takes the XCD's next tile when it is done.  Every 16-byte chunk of a
+// tile's footprint is a request to the XCD's L2 (128-byte lines, set-associative LRU); a miss is one 128-byte fabric
+// read.  Output lines are allocated in the L2 as the stores would.  Prints lines fetched vs the source size.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#include "t360_plan.h"
+
+namespace {
+struct L2 {
+  int sets, ways;
+  std::vector<uint64_t> tag;
+  std::vector<uint32_t> age;
+  uint32_t clock = 0;
+  long long miss = 0, hit = 0;
+  L2(int bytes, int ways_) : ways(ways_) {
+    sets = bytes / 128 / ways;
+    tag.assign((size_t)sets * ways, ~0ull);
+    age.assign((size_t)sets * ways, 0);
+  }
+  bool touch(uint64_t line, bool count) {
+    // hash the set index a little: rows 30 lines apart must not pile onto few sets
+    const uint64_t h = line ^ (line >> 11) ^ (line >> 22);
+    const size_t s = (size_t)(h % (uint64_t)sets) * ways;
+    clock++;
+    int victim = 0;
+    uint32_t oldest = 0xffffffffu;
+    for (int w = 0; w < ways; w++) {
+      if (tag[s + w] == line) {
+        age[s + w] = clock;
+        if (count) hit++;
+        return true;
+      }
+      if (age[s + w] < oldest) oldest = age[s + w], victim = w;
+    }
+    tag[s + victim] = line;
+    age[s + victim] = clock;
+    if (count) miss++;
+    return false;
+  }
+};
+
+struct SimTile {
+  int plane;                     // 0 Y, 1 U, 2 V
+  std::vector<uint32_t> chunks;  // distinct (row << 12 | col16)
+  int ox, oy, w, h;
+};
+}  // namespace
+
+
+static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc, int dhc,
+                        int swc, int shc, int ks, int max_pieces, int waves, int order, std::vector<SimTile>* tiles, int* ndirect) {
+  using namespace t360;
+  HostGatherPlan plan[2];
+  for (int k = 0; k < 2; k++) {
+    PlanOptions o;
+    o.ks = ks;
+    o.max_pieces = max_pieces;
+    o.waves = waves;
+    o.order = order;
+    if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return false;
+  }
+  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  *ndirect = plan[0].ndirect + 2 * plan[1].ndirect;
+  for (int pl = 0; pl < 3; pl++) {
+    const HostGatherPlan& p = plan[pl ? 1 : 0];
+    for (int ti = 0; ti < p.ntiles; ti++) {
+      SimTile t;
+      t.plane = pl;
+      const TileDesc& d = p.tiles[(size_t)ti];
+      t.ox = d.ox; t.oy = d.oy;
+      t.w = d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.h = d.kind == kTileStrip128 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
+      const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
+      uint32_t prev = ~0u;
+      for (int pos = 0; pos < d.pieces * kPieceChunks; pos++)
+        if (tc[pos] != prev) t.chunks.push_back(tc[pos]), prev = tc[pos];
+      tiles->push_back(std::move(t));
+    }
+  }
+  return true;
+}
+
+// Replay of a measured launch: item i = (tile, f0, f1, xcd, t0, t1) -- frame f of the item is requested at
+// t0 + (t1 - t0) * (f - f0) / (f1 - f0).  Returns fabric read lines.
+extern "C" long long t360_l2replay(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc,
+                                   int dhc, int swc, int shc, int ks, int max_pieces, int waves, int order, int l2_bytes, int ways,
+                                   int nitems, const int* item_tile, const int* item_f0, const int* item_f1, const int* item_xcd,
+                                   const double* item_t0, const double* item_t1, long long* out) {
+  std::vector<SimTile> tiles;
+  int ndirect = 0;
+  if (!build_tiles(lut_y, dwy, dhy, swy, shy, lut_c, dwc, dhc, swc, shc, ks, max_pieces, waves, order, &tiles, &ndirect)) return -1;
+  const long long ybytes = (long long)swy * shy, cbytes = (long long)swc * shc, frame_in = ybytes + 2 * cbytes;
+  const long long oy_bytes = (long long)dwy * dhy, oc_bytes = (long long)dwc * dhc, frame_out = oy_bytes + 2 * oc_bytes;
+  const uint64_t out_base = (uint64_t)1 << 40;
+  long long misses = 0, hits = 0;
+  for (int xcd = 0; xcd < 8; xcd++) {
+    struct Ev { double t; int item, f; };
+    std::vector<Ev> ev;
+    for (int i = 0; i < nitems; i++) {
+      if (item_xcd[i] != xcd || item_tile[i] < 0 || item_tile[i] >= (int)tiles.size()) continue;
+      const int nf = item_f1[i] - item_f0[i];
+      for (int f = 0; f < nf; f++) ev.push_back({item_t0[i] + (item_t1[i] - item_t0[i]) * f / nf, i, item_f0[i] + f});
+    }
+    std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t; });
+    L2 l2(l2_bytes, ways);
+    for (const Ev& e : ev) {
+      const SimTile& t = tiles[(size_t)item_tile[e.item]];
+      const long long pbase = (long long)e.f * frame_in + (t.plane == 0 ? 0 : t.plane == 1 ? ybytes : ybytes + cbytes);
+      const int stride = t.plane ? swc : swy;
+      for (uint32_t c : t.chunks) l2.touch((uint64_t)(pbase + (long long)(c >> 12) * stride + (long long)(c & 4095u) * 16) >> 7, true);
+      const long long obase = (long long)e.f * frame_out + (t.plane == 0 ? 0 : t.plane == 1 ? oy_bytes : oy_bytes + oc_bytes);
+      const int ostride = t.plane ? dwc : dwy;
+      for (int y = 0; y < t.h; y++)
+        for (int x = 0; x < t.w; x += 128)
+          l2.touch((out_base + (uint64_t)(obase + (long long)(t.oy + y) * ostride + t.ox + x)) >> 7, false);
+    }
+    misses += l2.miss;
+    hits += l2.hit;
+  }
+  out[0] = misses;
+  out[1] = hits;
+  out[2] = (long long)tiles.size();
+  out[3] = ndirect;
+  return misses;
+}
+
+// plans: luma + chroma.  Returns fabric read lines; out[0..7] = stats
+extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc,
+                                int dhc, int swc, int shc, int ks, int max_pieces, int waves, int order, int nframes, int slots,
+                                int l2_bytes, int ways, int jitter, int fpb, int lead, long long* out) {
+  using namespace t360;
+  HostGatherPlan plan[2];
+  for (int k = 0; k < 2; k++) {
+    PlanOptions o;
+    o.ks = ks;
+    o.max_pieces = max_pieces;
+    o.waves = waves;
+    o.order = order;
+    if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return -1;
+  }
+  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  std::vector<SimTile> tiles;
+  long long staged_chunks = 0;
+  for (int pl = 0; pl < 3; pl++) {
+    const HostGatherPlan& p = plan[pl ? 1 : 0];
+    for (int ti = 0; ti < p.ntiles; ti++) {
+      SimTile t;
+      t.plane = pl;
+      const TileDesc& d = p.tiles[(size_t)ti];
+      t.ox = d.ox; t.oy = d.oy;
+      t.w = d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.h = d.kind == kTileStrip128 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
+      const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
+      uint32_t prev = ~0u;
+      for (int pos = 0; pos < d.pieces * kPieceChunks; pos++)
+        if (tc[pos] != prev) t.chunks.push_back(tc[pos]), prev = tc[pos];
+      staged_chunks += (long long)t.chunks.size();
+      tiles.push_back(std::move(t));
+    }
+  }
+  const int total = (int)tiles.size();
+  const long long ybytes = (long long)swy * shy, cbytes = (long long)swc * shc;
+  const long long frame_in = ybytes + 2 * cbytes;
+  const long long oy_bytes = (long long)dwy * dhy, oc_bytes = (long long)dwc * dhc;
+  const long long frame_out = oy_bytes + 2 * oc_bytes;
+  const uint64_t out_base = (uint64_t)1 << 40;
+  long long misses = 0, hits = 0, wr_lines = 0;
+  double tend = 0;
+  std::mt19937 rng(12345);
+  for (int xcd = 0; xcd < 8; xcd++) {
+    const int q = total >> 3, rem = total & 7;
+    const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
+    L2 l2(l2_bytes, ways);
+    struct Slot { int tile = -1, f = 0, f1 = 0, wait = 0, rot = 0, done = 0; };
+    int front = 0;
+    const double startup = 5.0;
+    std::vector<Slot> slot((size_t)slots);
+    // work items: (tile, f0, f1) in order
+    struct Item { int tile, f0, f1; };
+    std::vector<Item> items;
+    if (fpb < 0) {  // frame-group major: the XCD sweeps all its tiles for frames 0..|fpb|-1, then the next group
+      for (int f0 = 0; f0 < nframes; f0 += -fpb)
+        for (int t = 0; t < len; t++) items.push_back({start + t, f0, std::min(nframes, f0 - fpb)});
+    } else {
+      for (int t = 0; t < len; t++)
+        for (int f0 = 0; f0 < nframes; f0 += fpb) items.push_back({start + t, f0, std::min(nframes, f0 + fpb)});
+    }
+    size_t next = 0;
+    // event driven: every slot has the time of its next frame; a frame of a tile of p pieces takes a + b*p (us), with
+    // `jitter` % of uniform noise; `lead` > 0: a workgroup may not run more than `lead` frames ahead of the slowest
+    // resident workgroup of its XCD (it polls every 0.2 us)
+    std::vector<double> tnext((size_t)slots, 0.0);
+    const double ta = 0.69, tb = 0.0234;
+    std::uniform_real_distribution<double> uni(-1.0, 1.0);
+    for (;;) {
+      int si = -1;
+      double best = 1e30;
+      for (int i = 0; i < slots; i++) {
+        Slot& s = slot[(size_t)i];
+        if ((s.tile < 0 || s.f >= s.f1) && next >= items.size()) { s.tile = -1; continue; }
+        if (tnext[(size_t)i] < best) best = tnext[(size_t)i], si = i;
+      }
+      if (si < 0) break;
+      Slot& s = slot[(size_t)si];
+      if (s.tile < 0 || s.f >= s.f1) {
+        s.tile = items[next].tile; s.f = items[next].f0; s.f1 = items[next].f1; next++;
+        tnext[(size_t)si] += startup;  // start-up
+        s.rot = 0;
+        if (lead < 0) {  // start at the frame the XCD's front is on (+ what it will advance during my start-up), wrap around
+          s.rot = (front + (int)(startup / 1.0)) % (s.f1 - s.f);
+        }
+        s.done = 0;
+        continue;
+      }
+      if (lead > 0) {
+        int slowest = 1 << 30;
+        for (int i = 0; i < slots; i++)
+          if (slot[(size_t)i].tile >= 0 && slot[(size_t)i].f < slot[(size_t)i].f1)
+            slowest = std::min(slowest, slot[(size_t)i].f);
+        if (s.f > slowest + lead) { tnext[(size_t)si] += 0.2; continue; }
+      }
+      const SimTile& t = tiles[(size_t)s.tile];
+      const int nfr = s.f1 - (s.f - s.done);
+      const int fr = (s.f - s.done) + (s.rot + s.done) % nfr;
+      if (lead < 0) front = fr;
+      const long long pbase = (long long)fr * frame_in + (t.plane == 0 ? 0 : t.plane == 1 ? ybytes : ybytes + cbytes);
+      const int stride = t.plane ? swc : swy;
+      for (uint32_t e : t.chunks) {
+        const long long a = pbase + (long long)(e >> 12) * stride + (long long)(e & 4095u) * 16;
+        l2.touch((uint64_t)a >> 7, true);
+      }
+      const long long obase = (long long)fr * frame_out + (t.plane == 0 ? 0 : t.plane == 1 ? oy_bytes : oy_bytes + oc_bytes);
+      const int ostride = t.plane ? dwc : dwy;
+      for (int y = 0; y < t.h; y++)
+        for (int x = 0; x < t.w; x += 128) {
+          l2.touch((out_base + (uint64_t)(obase + (long long)(t.oy + y) * ostride + t.ox + x)) >> 7, false);
+          wr_lines++;
+        }
+      s.f++;
+      s.done++;
+      const double pieces = (double)t.chunks.size() / 64.0;
+      tnext[(size_t)si] += (ta + tb * pieces) * (1.0 + 0.01 * jitter * uni(rng));
+      tend = std::max(tend, tnext[(size_t)si]);
+    }
+    misses += l2.miss;
+    hits += l2.hit;
+  }
+  out[0] = misses;
+  out[1] = hits;
+  out[2] = staged_chunks;
+  out[3] = total;
+  out[4] = frame_in;
+  out[5] = wr_lines;
+  out[6] = (long long)(tend * 1000);
+  return misses;
+}

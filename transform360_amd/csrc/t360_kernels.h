@@ -63,10 +63,14 @@ struct TiledArgs {
   int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
   int ring_kb;              // LDS per workgroup in KiB and waves per workgroup (4 or 8): select the kernel instantiation
   int waves;
+  int pace;                 // > 0: frame clock period in ticks of the 100 MHz wall clock (t360_remap_tiled.hip)
+  int pace_lead;            // frames a workgroup may run ahead of the frame clock
+  int fg_major;             // work items ordered frame group first (every XCD sweeps its tiles once per group of frames)
 #ifdef T360_INSTRUMENT
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
                             // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B
   unsigned long long* trace;  // instrumented build only: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
+  unsigned long long* phases; // instrumented build only: 2 x 8 cycle sums per workgroup (T360_PHASES)
 #endif
   TiledPlane plane[4];
 };

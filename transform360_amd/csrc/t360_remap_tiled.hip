@@ -59,6 +59,9 @@ constexpr int kMaxSlots = T360_MAX_SLOTS;
 #define T360_DUAL 0
 #endif
 constexpr bool dual_copy(int ks) { return T360_DUAL != 0 && ks != 1; }
+#ifndef T360_ASMREAD
+#define T360_ASMREAD 1
+#endif
 template <int P, bool DUAL>
 struct Slot {
   // copy B: the same bytes 4 further (odd dwords become 8-byte aligned) and half a bank row (32 dwords) apart,
@@ -324,6 +327,14 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
         for (int r = 0; r < ROWS; r++) {
           if (dual_copy(KS)) {
             win[p][r] = *reinterpret_cast<const uint64_t*>(lds + s.addr[p0 + p][r] + SLOT);
+          } else if (T360_ASMREAD && WIN == 1) {
+            // the ring slot as the IMMEDIATE offset of two ds_read_b32 (16 bits; ds_read2_b32 has 8-bit offsets, so for
+            // slots 1.. hipcc adds the slot base to every address register first: 16 VALU per 4 pixels and frame)
+            uint32_t d0, d1;
+            const uint32_t la = (uint32_t)(uintptr_t)lds + s.addr[p0 + p][r];  // loop invariant: hoisted out of the frame loop
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d0) : "v"(la), "n"(SLOT));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d1) : "v"(la), "n"(SLOT + 4));
+            win[p][r] = (uint64_t)d0 | ((uint64_t)d1 << 32);
           } else {
             // two aligned dwords (the slot base does not fit ds_read2_b32's 8-bit offsets: two ds_read_b32)
             const uint32_t d0 = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT);
@@ -332,6 +343,7 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
           }
           if (WIN == 2) ext[p][r] = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT + 8);
         }
+      if (T360_ASMREAD && WIN == 1 && !dual_copy(KS)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count asm loads
       // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
 #pragma unroll
       for (int p = 0; p < G; p++)
@@ -515,7 +527,7 @@ __device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
 // the (older) stores do.
 template <int NPX, int KS, int GROUP, int P, int K, int WAVES>
 __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, const TileFetch& tf,
-                                           const uint8_t* __restrict__ lds, int f0, int f1) {
+                                           const uint8_t* __restrict__ lds, int f0, int f1, unsigned long long* clock_slot) {
   constexpr bool DUAL = dual_copy(KS);
   using R = Slot<P, DUAL>;
   const int lane = threadIdx.x & 63;
@@ -542,37 +554,87 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   };
   const int per_frame = DUAL ? 2 * mine : mine;  // my DMA instructions per frame
   const int nf = f1 - f0;
+  // Frame clock (a.pace > 0, in ticks of the 100 MHz wall clock): every workgroup of the launch walks its frames in
+  // the order the CLOCK dictates -- it starts at frame (t / pace) mod nf, wraps around, and never runs ahead of the
+  // clock -- so that tiles which share source lines ask for them within a frame time of each other and the second
+  // request finds the line in the XCD's L2 (which keeps ~4 us of the XCD's stream; tools/ubench/l2_probe.hip).
+  int rot = 0;
+  unsigned long long t_next = 0;
+  if (a.pace > 0) {
+    if (threadIdx.x == 0) *clock_slot = (unsigned long long)wall_clock64();
+    __syncthreads();
+    const unsigned long long a0 = *clock_slot / (unsigned)a.pace;
+    rot = (int)(a0 % (unsigned)nf);
+    t_next = (a0 + 1 - (unsigned)a.pace_lead) * (unsigned)a.pace;  // pace_lead frames ahead of the clock are allowed
+  }
+  rot = __builtin_amdgcn_readfirstlane(rot);
+  auto frame_of = [&](int j) {  // j-th frame of this workgroup's walk
+    const int f = rot + j;
+    return f0 + (f >= nf ? f - nf : f);
+  };
   T360_MARK(a, 1);  // tile tables here
   // weights first (they depend on the pixel words only), then the prologue DMA, then wait for both
   PixelSetup<NPX, KS> px;
   load_pixels<NPX, KS, P>(tf, a.wpack, px);
 #pragma unroll
   for (int j = 0; j < K - 1; j++)
-    if (j < nf) issue(f0 + j, j * R::kSlot);
+    if (j < nf) issue(frame_of(j), j * R::kSlot);
   pin_pixels<NPX, KS>(px);
   T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
   const uint32_t doff = out_pos<NPX>(pl, t, dword_store);
-  uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);  // the store uses SGPR base + VGPR offset
+  uint8_t* const __restrict__ dst0 = uniform_ptr(pl.dst);  // the store uses SGPR base + VGPR offset
   uint32_t pending = 0;
+#ifdef T360_INSTRUMENT
+  // phase profile (T360_PHASES=file): shader-clock cycles this wave spent in each part of the frame loop, summed over
+  // the frames: [0] pace wait, [1] waiting for its DMA pieces, [2] at the barrier, [3] store + DMA issue, [4] gather
+  unsigned long long ph_acc[5] = {0, 0, 0, 0, 0}, ph_last = a.phases ? __builtin_readcyclecounter() : 0;
+#define T360_PHASE(k)                                          \
+  if (a.phases) {                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ph_acc[(k + 4) % 5] += now_ - ph_last;                     \
+    ph_last = now_;                                            \
+  }
+#else
+#define T360_PHASE(k)
+#endif
   for (int i = 0; i < nf; i += K) {
 #define T360_STEP(S)                                                                                       \
     if constexpr (S < K) if (i + S < nf) {                                                                 \
-      wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
-      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
-      if (i + S > 0) {                                                                                     \
-        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                          \
-        d += pl.dst_frame_bytes;                                                                           \
+      if (a.pace > 0) {                                                                                    \
+        while ((unsigned long long)wall_clock64() < t_next) __builtin_amdgcn_s_sleep(1);                   \
+        t_next += (unsigned)a.pace;                                                                        \
       }                                                                                                    \
-      if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
+      T360_PHASE(0);                                                                                       \
+      wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
+      T360_PHASE(1);                                                                                       \
+      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
+      T360_PHASE(2);                                                                                       \
+      if (i + S > 0 && has_px)                                                                             \
+        emit<NPX, KS>(px, pending, dst0 + (size_t)frame_of(i + S - 1) * pl.dst_frame_bytes, doff, pl.dstride, dword_store); \
+      if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(frame_of(i + S + K - 1), ((S + K - 1) % K) * R::kSlot);  \
+      T360_PHASE(3);                                                                                       \
       if (has_px && !T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store); \
+      asm volatile("" : "+v"(pending));                                                                    \
+      T360_PHASE(4);                                                                                       \
       if (i + S == 0) T360_MARK(a, 3);                                                                     \
       if (i + S == 1) T360_MARK(a, 4);                                                                     \
     }
     T360_STEP(0) T360_STEP(1) T360_STEP(2) T360_STEP(3)
 #undef T360_STEP
   }
-  if (nf > 0 && has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
+  if (nf > 0 && has_px) emit<NPX, KS>(px, pending, dst0 + (size_t)frame_of(nf - 1) * pl.dst_frame_bytes, doff, pl.dstride, dword_store);
+#ifdef T360_INSTRUMENT
+  if (a.phases && (wave == 0 || wave == WAVES - 1) && lane == 0) {
+    unsigned long long* o = a.phases + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[k] = ph_acc[k];
+    o[5] = (unsigned long long)nf;
+    o[6] = ((unsigned long long)(unsigned)t.kind << 32) | (unsigned)t.pieces;
+  }
+#endif
+#undef T360_PHASE
   T360_MARK(a, 5);
 }
 
@@ -701,7 +763,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     // instead of frames_per_block (a quarter of the grid costs a few extra start-ups, the tail shrinks 4x).
     const int len_tail = (len * a.tail_percent) / 100, len_head = len - len_tail;
     int fpb;
-    if (k < len_head * a.groups) {
+    if (a.fg_major) {
+      // frame-group major: the XCD sweeps ALL its tiles for frames 0 .. fpb-1, then for the next group: resident
+      // workgroups are then list neighbours on the same frames that started within microseconds of each other
+      g = k / len;
+      if (g >= a.groups) return;
+      b = start + (k - g * len);
+      fpb = a.frames_per_block;
+    } else if (k < len_head * a.groups) {
       const int t_local = k / a.groups;
       b = start + t_local;
       g = k - t_local * a.groups;
@@ -745,15 +814,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
   if (T360_DBG(a, 3) && t.kind == kTileStaged16) return;
   if (T360_DBG(a, 4) && t.kind != kTileStaged16) return;
   const int pieces = (int)t.pieces;
+  unsigned long long* clock_slot = reinterpret_cast<unsigned long long*>(lds + RINGKB * 1024);  // 64 bytes behind the ring
   if (KS == 8 || t.kind == kTileStaged16) {
 #define T360_TILE1(P) \
-    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1, clock_slot);
     T360_FOR_CLASS(pieces, T360_TILE1)
 #undef T360_TILE1
   } else {
 #define T360_TILE4(P)                                                        \
     if constexpr (Cls<RINGKB, P, DUAL>::K >= 2)                               \
-      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
+      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1, clock_slot);
     T360_FOR_CLASS(pieces, T360_TILE4)
 #undef T360_TILE4
   }
@@ -772,7 +842,7 @@ constexpr int max_pieces_of() {
 
 template <int KS, int RINGKB, int WAVES>
 hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
-  constexpr int lds_bytes = RINGKB * 1024;
+  constexpr int lds_bytes = RINGKB * 1024 + 64;  // the ring + the word the frame clock is broadcast through
   if (a.max_pieces > max_pieces_of<RINGKB, dual_copy(KS)>()) return hipErrorInvalidValue;
   if (lds_bytes > 64 * 1024) {
     // per device and cheap: not cached (handles may live on several devices of one process)
@@ -782,7 +852,7 @@ hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
   }
   const int per_xcd = (a.total_tiles + 7) / 8;
   const int tail = (per_xcd * a.tail_percent) / 100;
-  const int items = (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;  // >= any XCD's item count
+  const int items = a.fg_major ? per_xcd * groups : (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;  // >= any XCD's item count
   hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB, WAVES>), dim3(a.direct_blocks + 8 * items, 1, 1), dim3(64 * WAVES),
                      (size_t)lds_bytes, stream, a);
   return hipGetLastError();

@@ -195,6 +195,9 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_TAIL_PCT")) tail_percent_ = atoi(e);
   if (const char* e = getenv("T360_SMALL_BATCH")) small_batch_ = atoi(e);
   if (const char* e = getenv("T360_TAIL_FRAMES")) tail_frames_ = atoi(e);
+  if (const char* e = getenv("T360_FG_MAJOR")) fg_major_ = atoi(e) != 0;
+  if (const char* e = getenv("T360_PACE")) pace_ticks_ = atoi(e);
+  if (const char* e = getenv("T360_PACE_LEAD")) pace_lead_ = atoi(e);
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
@@ -1017,6 +1020,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.tail_frames = std::max(1, std::min(fused.frames_per_block, tail_frames_));
     fused.tail_groups = (n_frames + fused.tail_frames - 1) / fused.tail_frames;
     fused.tail_percent = fused.tail_groups > fused.groups ? tail_percent_ : 0;
+    fused.fg_major = fg_major_ ? 1 : 0;
+    fused.pace = pace_ticks_;
+    fused.pace_lead = pace_lead_;
+    if (fused.fg_major) fused.tail_percent = 0;
     fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
 #ifdef T360_INSTRUMENT
     t360::DeviceBuffer trace;
@@ -1024,9 +1031,23 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * (((fused.total_tiles + 7) / 8) + 1) * std::max(fused.groups, fused.tail_groups);
     if (trace_path && trace.reserve(nwg * 64) && hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
       fused.trace = trace.as<unsigned long long>();
+    t360::DeviceBuffer phases;
+    const char* phases_path = getenv("T360_PHASES");
+    if (phases_path && phases.reserve(nwg * 128) && hipMemsetAsync(phases.as<void>(), 0, nwg * 128, stream_) == hipSuccess)
+      fused.phases = phases.as<unsigned long long>();
 #endif
     const bool ok = check(launch_remap_tiled(fused, stream_), "tiled remap launch");
 #ifdef T360_INSTRUMENT
+    if (fused.phases) {
+      std::vector<unsigned long long> host(nwg * 16);
+      if (hipStreamSynchronize(stream_) == hipSuccess &&
+          hipMemcpy(host.data(), phases.as<void>(), nwg * 128, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(phases_path, "wb")) {
+          fwrite(host.data(), 8, host.size(), f);
+          fclose(f);
+        }
+      }
+    }
     if (fused.trace) {
       std::vector<unsigned long long> host(nwg * 8);
       if (hipStreamSynchronize(stream_) == hipSuccess &&

@@ -146,6 +146,9 @@ class VideoFrameTransform {
   int tail_percent_ = 12, tail_frames_ = 16;  // the last eighth of every XCD's tiles walks the batch in runs of 16 frames
                                                // (short workgroups drain the launch; each pays the ~5 us start-up again,
                                                // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
+  int pace_lead_ = 0;
+  int pace_ticks_ = 0;         // frame clock period of the tiled gather in 10 ns ticks (0: free running)
+  bool fg_major_ = false;      // frame-group major work order (t360_remap_tiled.hip)
   int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
   static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
