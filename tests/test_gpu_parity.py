@@ -309,15 +309,12 @@ def test_host_buffers_that_come_and_go():
 # runs of ring geometries and plan options; every one of those switches must leave the pixels alone.  It is a second
 # library, so it runs in a child process (tests/run_variants.py) with T360_LIB pointing at it.
 VARIANTS = [
-    {"T360_WAVES": "4"}, {"T360_WAVES": "4", "T360_MAX_PIECES": "8"},
-    {"T360_MAX_PIECES": "8"}, {"T360_MAX_PIECES": "4"}, {"T360_MAX_PIECES": "16"},
+    {"T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "12"}, {"T360_WAVES": "4", "T360_RING_KB": "26", "T360_MAX_PIECES": "12"},
+    {"T360_MAX_PIECES": "8"}, {"T360_MAX_PIECES": "4"}, {"T360_WAVES": "4", "T360_RING_KB": "38", "T360_MAX_PIECES": "16"},
     {"T360_ROW_ALIGN": "1"}, {"T360_ROW_ALIGN": "4"}, {"T360_STRIPS": "120"}, {"T360_STRIPS": "1000"}, {"T360_WIDE64": "0"},
     {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
-    {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_MAX_PIECES": "8"}, {"T360_FRAMES_PER_BLOCK": "5"},
-    {"T360_FRAMES_PER_BLOCK": "4", "T360_TAIL_FRAMES": "1", "T360_TAIL_PCT": "50"}, {"T360_DEBUG": "64"},
-    {"T360_WGS_PER_XCD": "1"}, {"T360_WGS_PER_XCD": "2", "T360_FRAMES_PER_BLOCK": "4"}, {"T360_WGS_PER_XCD": "3", "T360_WAVES": "4"},
-    {"T360_WGS_PER_XCD": "1", "T360_FRAMES_PER_BLOCK": "4", "T360_TAIL_FRAMES": "1", "T360_TAIL_PCT": "40"},
-    {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"}, {"T360_NO_WIDE_LOWPASS": "1"}, {"T360_SMALL_BATCH": "1000"},
+    {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
+    {"T360_NO_WIDE_LOWPASS": "1"}, {"T360_SMALL_BATCH": "1000"},
 ]
 
 
@@ -340,7 +337,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
     from transform360_amd import _lib
     assert _lib.load().T360_buildFlags() == 0
     # a switch of the instrumented build must be inert here: same kernel instantiation as without it
-    monkeypatch.setenv("T360_WAVES", "4")
+    monkeypatch.setenv("T360_RING_KB", "50")
     monkeypatch.setenv("T360_NO_TILED", "1")
     import torch
     with T.VideoFrameTransform(filter_defaults(enable_low_pass_filter=0)) as t:
@@ -349,7 +346,7 @@ def test_shipped_library_reads_no_environment(T, oracle_mod, monkeypatch):
         dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
         _ready()
         assert t.transformFramePlane(src, dst, 0)
-        assert t.lastKernel() == "remap_tiled_kernel<4, 4>"  # a single frame: the short-batch plan (64 frames: <4, 8>)
+        assert t.lastKernel() == "remap_tiled_kernel<4, 38, 4>"  # a single frame: the short-batch plan (64 frames: <4, 76, 8>)
 
 
 # ---------------------------------------------------------------- full-size configs (BASELINE)

@@ -60,14 +60,13 @@ struct TiledArgs {
   int tail_percent;         // the last tail_percent % of every XCD's tiles use runs of tail_frames frames instead
   int tail_frames, tail_groups;
   int direct_blocks;        // work items reserved for direct tiles: total_direct * groups, rounded up to a multiple of 8
-  int max_pieces;           // the plan's staging budget per tile (1 KiB pieces) = stride of its chunk tables
-  int waves;                // waves per workgroup (4 or 8): selects the kernel instantiation
-  uint32_t* tickets;        // 8 work counters (one per XCD list), never reset
-  uint32_t ticket_base[8];  // first ticket of this launch per list
-  int wgs_per_xcd;          // persistent workgroups per XCD (what is resident at once: CUs per XCD x workgroups per CU)
+  int max_pieces;           // the plan's staging budget per tile and copy (1 KiB pieces)
+  int ring_kb;              // LDS per workgroup in KiB and waves per workgroup (4 or 8): select the kernel instantiation
+  int waves;
 #ifdef T360_INSTRUMENT
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
-                            // bit2 skip direct tiles; bit6 (right pixels): items are not pipelined into each other
+                            // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B
+  unsigned long long* trace;  // instrumented build only: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   unsigned long long* phases; // instrumented build only: 2 x 8 cycle sums per workgroup (T360_PHASES)
 #endif
   TiledPlane plane[4];
@@ -76,10 +75,7 @@ struct TiledArgs {
 // Every plane's source must be 16-byte friendly (base, stride, frame distance, width).
 hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream);
 // the instantiation launch_remap_tiled() picks for these parameters (reporting)
-const char* remap_tiled_kernel_name(int ks, int waves);
-// largest tile (1 KiB pieces) the instantiation for (ks, waves) can stage, and how many of its workgroups fit a CU
-int tiled_max_pieces(int ks, int waves);
-int tiled_workgroups_per_cu(int ks, int waves);
+const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves);
 
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {

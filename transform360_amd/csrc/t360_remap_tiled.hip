@@ -44,34 +44,43 @@ namespace {
 
 
 // ---- ring geometry (compile time) -------------------------------------------------------------
-// A workgroup owns LDSKB KiB of LDS: a ring of K slots of P KiB (+ 64 bytes) each -- P = the largest tile of the plan
-// the instantiation serves, in 1 KiB DMA pieces -- and, behind the ring, the PREFETCH area: per wave the chunk entries
-// of its pieces of the NEXT tile and that tile's descriptor (see the kernel).  Slot addresses are compile-time
-// constants: the frame loop is unrolled over the K slots and a slot is the immediate offset of the consumer's ds_read.
+// A workgroup owns RINGKB KiB of LDS.  A tile of p pieces (1 KiB of staged source each) uses the smallest slot
+// class P >= p; its ring then holds K = min(4, ring / slot) frames.  Slot sizes are compile-time constants so
+// that the slot base is an immediate of the consumer's ds_read (the frame loop is unrolled over the K slots):
+// most tiles stage 4-8 KiB and keep 4 frames in the ring, the few large ones near the poles 2-3.
 #ifndef T360_MAX_SLOTS
 #define T360_MAX_SLOTS 3
 #endif
+constexpr int kMaxSlots = T360_MAX_SLOTS;
+// T360_DUAL: 1 = every chunk is staged twice (copy B four bytes further) so that each stencil-row window is ONE aligned
+// ds_read_b64; 0 = one copy, two aligned ds_read_b32 per window: twice the LDS read cycles, but half the LDS per frame in
+// flight.  The gather is bound by bytes in flight (HBM latency x bandwidth), not by LDS cycles: 0 measured faster.
+#ifndef T360_DUAL
+#define T360_DUAL 0
+#endif
+constexpr bool dual_copy(int ks) { return T360_DUAL != 0 && ks != 1; }
 #ifndef T360_ASMREAD
 #define T360_ASMREAD 1
 #endif
-template <int KS, int WAVES>
-struct Ring {
-#ifndef T360_P8
-#define T360_P8 24
-#endif
-#ifndef T360_LDS8
-#define T360_LDS8 80
-#endif
-  static constexpr int P = KS == 8 ? 16 : (WAVES == 8 ? T360_P8 : 12);  // = the plan's max_pieces (t360_transform.cpp)
-  static constexpr int LDSKB = WAVES == 8 ? T360_LDS8 : 40;             // 2 x 80 / 4 x 40 KiB fill a CU's 160 KiB
-  static constexpr int kSlot = P * 1024 + 64;
-  static constexpr int MAXJ = (P + WAVES - 1) / WAVES;              // pieces one wave moves per frame (<= 4)
-  static constexpr int kPfWave = MAXJ * 256 + 64;                   // prefetch area of one wave (+ descriptor + ticket word)
-  static constexpr int kFit = (LDSKB * 1024 - WAVES * kPfWave) / kSlot;
-  static constexpr int K = kFit > T360_MAX_SLOTS ? T360_MAX_SLOTS : kFit;
-  static constexpr int kPfBase = K * kSlot;
-  static_assert(K >= 2 && MAXJ <= 4, "ring geometry");
+template <int P, bool DUAL>
+struct Slot {
+  // copy B: the same bytes 4 further (odd dwords become 8-byte aligned) and half a bank row (32 dwords) apart,
+  // so that the A and B qwords of neighbouring lanes do not meet on the same banks
+  static constexpr int kCopyB = P * 1024 + 4 + 128;
+  static constexpr int kSlot = DUAL ? 2 * P * 1024 + 128 + 64 : P * 1024 + 64;
 };
+template <int RINGKB, int P, bool DUAL>
+struct Cls {
+  static constexpr int kFit = RINGKB * 1024 / Slot<P, DUAL>::kSlot;
+  static constexpr int K = kFit > kMaxSlots ? kMaxSlots : kFit;  // < 2: the class does not fit this ring
+};
+// smallest class that holds `pieces`
+#define T360_FOR_CLASS(pieces, F)    \
+  if ((pieces) <= 8) { F(8) }        \
+  else if ((pieces) <= 12) { F(12) } \
+  else if ((pieces) <= 16) { F(16) } \
+  else if ((pieces) <= 24) { F(24) } \
+  else { F(32) }
 
 // ---- per-pixel geometry -----------------------------------------------------------------------
 // KS = taps per axis: 1 nearest, 2 bilinear, 4 bicubic, 8 Lanczos4.  A stencil row is read as WIN 4-byte
@@ -95,11 +104,33 @@ struct PixelSetup {
   bool live[NPX];          // pixel inside the plane (partial tiles)
 };
 
-// What a lane needs of the tile's tables for its pixels
+// What a workgroup fetches from its tile index alone, before (and in parallel with) the tile descriptor.
 struct TileFetch {
   uint32_t words[4];  // pixel words of this lane (16x16 tiles: words[0])
+  uint32_t chunk[4];  // chunk entries of this lane in pieces wave, wave + WAVES, wave + 2 WAVES, wave + 3 WAVES
   uint32_t rowdw;     // dword `lane` of the row table = row_base of box rows 2*lane and 2*lane + 1
 };
+
+template <int KS, int WAVES>
+__device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, int max_pieces) {
+  TileFetch f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (KS == 8) {
+    f.words[0] = tid < 256 ? pl.tlut[(size_t)tile * tile_words(KS, WAVES) + tid] : kWordDead;
+    f.words[1] = f.words[2] = f.words[3] = kWordDead;
+  } else {
+    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)tile * tile_words(KS, WAVES))[tid];
+    f.words[0] = v.x; f.words[1] = v.y; f.words[2] = v.z; f.words[3] = v.w;
+  }
+  const uint32_t* __restrict__ tc = pl.chunks + (size_t)tile * tile_chunk_dwords(max_pieces);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int piece = wave + WAVES * j;
+    f.chunk[j] = piece < max_pieces ? tc[piece * kPieceChunks + lane] : 0u;
+  }
+  f.rowdw = tc[max_pieces * kPieceChunks + lane];
+  return f;
+}
 
 // row_base of box row r out of the wave-distributed row table (lane r/2 holds rows r & ~1 and r | 1)
 __device__ __forceinline__ int row_base_of(uint32_t rowdw, int r) {
@@ -107,7 +138,7 @@ __device__ __forceinline__ int row_base_of(uint32_t rowdw, int r) {
   return (r & 1) ? (v >> 16) : (int)(int16_t)v;
 }
 
-template <int NPX, int KS>
+template <int NPX, int KS, int P>
 __device__ __forceinline__ void load_pixels(const TileFetch& tf, const uint32_t* __restrict__ wpack, PixelSetup<NPX, KS>& s) {
   constexpr int NW = Stencil<KS>::NW;
 #pragma unroll
@@ -120,8 +151,11 @@ __device__ __forceinline__ void load_pixels(const TileFetch& tf, const uint32_t*
 #pragma unroll
     for (int k = 0; k < KS; k++) {
       const int off = row_base_of(tf.rowdw, (row + k) & (kBoxMaxRows - 1)) * kStageChunk + x;
-      // KS == 1 reads the byte itself; otherwise the aligned dword the window starts in (and the next one)
-      s.addr[p][k] = !s.live[p] ? 0u : KS == 1 ? (uint32_t)off : (uint32_t)(off & ~3);
+      // KS == 1 reads the byte itself from copy A; otherwise the aligned qword of copy A or B that holds the window
+      s.addr[p][k] = !s.live[p]    ? 0u
+                     : KS == 1      ? (uint32_t)off
+                     : dual_copy(KS) ? (uint32_t)((off & ~3) + ((off & 4) ? Slot<P, true>::kCopyB : 0))
+                                     : (uint32_t)(off & ~3);
     }
     s.hb[p] = 0;
     if (NW > 0) {
@@ -222,9 +256,11 @@ __device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // the value IS w
   return reinterpret_cast<uint8_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
 }
-// values that ARE wave-uniform but reach hipcc through paths it calls divergent (the ticket an item is derived from comes
-// out of LDS): inline asm wants them in SGPRs
-#define T360_UNIFORM(p) uniform_ptr(p)
+#ifdef T360_INSTRUMENT
+#define T360_UNIFORM(p) uniform_ptr(p)  // the divergent trace branches of this build hide the uniformity from hipcc
+#else
+#define T360_UNIFORM(p) (p)
+#endif
 __device__ __forceinline__ void store_dword(uint8_t* base, uint32_t off, uint32_t v) {
   asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
@@ -289,7 +325,9 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
       for (int p = 0; p < G; p++)
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
-          if (T360_ASMREAD && WIN == 1) {
+          if (dual_copy(KS)) {
+            win[p][r] = *reinterpret_cast<const uint64_t*>(lds + s.addr[p0 + p][r] + SLOT);
+          } else if (T360_ASMREAD && WIN == 1) {
             // the ring slot as the IMMEDIATE offset of two ds_read_b32 (16 bits; ds_read2_b32 has 8-bit offsets, so for
             // slots 1.. hipcc adds the slot base to every address register first: 16 VALU per 4 pixels and frame)
             uint32_t d0, d1;
@@ -305,7 +343,7 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
           }
           if (WIN == 2) ext[p][r] = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT + 8);
         }
-      if (T360_ASMREAD && WIN == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count asm loads
+      if (T360_ASMREAD && WIN == 1 && !dual_copy(KS)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count asm loads
       // keep hipcc from sinking the reads next to their uses (it would serialise the round trips)
 #pragma unroll
       for (int p = 0; p < G; p++)
@@ -464,330 +502,120 @@ __device__ __forceinline__ void frame_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// One dword per active lane, global -> LDS by DMA (lane l lands at lds_dst + 4 l): the prefetches of the NEXT tile's
-// tables.  Like the frame DMA, invisible to hipcc's wait counting and free of VGPR results.
-__device__ __forceinline__ void dma_dword(const void* base, uint32_t voff, uint32_t lds_dst) {
-  const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);
-  const uint8_t* sbase = uniform_ptr(const_cast<uint8_t*>(static_cast<const uint8_t*>(base)));  // the value IS wave-uniform
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
-}
-
 #ifdef T360_INSTRUMENT
 #define T360_DBG(a, bit) (((a).debug >> (bit)) & 1)
+// per-workgroup phase timestamps of the instrumented build (T360_TRACE=file; tools/trace_stats.py)
+__device__ __forceinline__ void trace_mark(const TiledArgs& a, int slot) {
+  if (a.trace && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    a.trace[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
+  }
+}
+#define T360_MARK(a, slot) trace_mark(a, slot)
 #else
 #define T360_DBG(a, bit) 0
+#define T360_MARK(a, slot)
 #endif
 
-// ---- work items --------------------------------------------------------------------------------------------------
-// Work items = (tile, run of frames).  Every XCD owns one contiguous range of the execution-ordered (Z-order) tile list
-// of all planes, so that neighbouring tiles -- whose footprints overlap by the stencil halo -- share an L2; the last
-// tail_percent % of the range walk the batch in shorter runs (tail_frames instead of frames_per_block): the items that
-// finish the launch are then short ones.  Item k of XCD x:
-struct Item {
-  int b;       // tile, counted over the staged tiles of all planes
-  int f0, f1;  // frames
-};
-__device__ __forceinline__ bool decode_item(const TiledArgs& a, int xcd, int k, Item* it) {
-  const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
-  const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
-  const int len_tail = (len * a.tail_percent) / 100, len_head = len - len_tail;
-  int fpb, g;
-  if (k < len_head * a.groups) {
-    const int t_local = k / a.groups;
-    it->b = start + t_local;
-    g = k - t_local * a.groups;
-    fpb = a.frames_per_block;
-  } else {
-    const int k2 = k - len_head * a.groups;
-    const int t_local = k2 / a.tail_groups;
-    if (t_local >= len_tail) return false;
-    it->b = start + len_head + t_local;
-    g = k2 - t_local * a.tail_groups;
-    fpb = a.tail_frames;
-  }
-  it->f0 = g * fpb;
-  it->f1 = min(it->f0 + fpb, a.nframes);
-  // the ticket came out of LDS: tell hipcc that what follows from it is wave-uniform (scalar registers, scalar branches)
-  it->b = __builtin_amdgcn_readfirstlane(it->b);
-  it->f0 = __builtin_amdgcn_readfirstlane(it->f0);
-  it->f1 = __builtin_amdgcn_readfirstlane(it->f1);
-  return true;
-}
-// the plane a tile belongs to (scalar selects: indexing a.plane[] with a run-time index would make hipcc copy the whole
-// argument block to scratch); returns the tile's index inside that plane's plan
-__device__ __forceinline__ int select_plane(const TiledArgs& a, int b, TiledPlane* pl) {
-  *pl = a.plane[0];
-  if (a.nplanes > 1 && b >= pl->ntiles) {
-    b -= pl->ntiles;
-    *pl = a.plane[1];
-    if (a.nplanes > 2 && b >= pl->ntiles) {
-      b -= pl->ntiles;
-      *pl = a.plane[2];
-      if (a.nplanes > 3 && b >= pl->ntiles) {
-        b -= pl->ntiles;
-        *pl = a.plane[3];
-      }
-    }
-  }
-  return b;
-}
-
-// one field of the plane a tile belongs to, by scalar selects (see select_plane); *b becomes the index inside the plane
-__device__ __forceinline__ int plane_of(const TiledArgs& a, int* b) {
-  int pi = 0;
-  if (a.nplanes > 1 && *b >= a.plane[0].ntiles) {
-    *b -= a.plane[0].ntiles;
-    pi = 1;
-    if (a.nplanes > 2 && *b >= a.plane[1].ntiles) {
-      *b -= a.plane[1].ntiles;
-      pi = 2;
-      if (a.nplanes > 3 && *b >= a.plane[2].ntiles) {
-        *b -= a.plane[2].ntiles;
-        pi = 3;
-      }
-    }
-  }
-  return pi;
-}
-#define T360_PLANE_FIELD(a, pi, field) \
-  ((pi) == 0 ? (a).plane[0].field : (pi) == 1 ? (a).plane[1].field : (pi) == 2 ? (a).plane[2].field : (a).plane[3].field)
-
-// ---- tickets: which item a workgroup takes next --------------------------------------------------------------------
-// One counter per XCD list, never reset: a launch's tickets start at ticket_base[xcd] (the host adds what a launch
-// consumes -- its items + 2 per workgroup -- after every launch).  Scalar atomics: device-coherent (checked:
-// tools/ubench/satomic_test.hip), counted by lgkmcnt -- they do not disturb the DMA ring's vmcnt bookkeeping.
-__device__ __forceinline__ uint32_t grab_tickets(uint32_t* ctr, uint32_t n) {
-  uint32_t v = n;
-  uint32_t* sctr = reinterpret_cast<uint32_t*>(uniform_ptr(reinterpret_cast<uint8_t*>(ctr)));
-  asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(sctr) : "memory");
-  return v;
-}
-// LDS words by explicit ds instructions (byte address inside the workgroup's LDS): what the DMA engine or another wave
-// wrote is invisible to hipcc, and a `volatile` access through a generic pointer would become a flat load behind
-// s_waitcnt vmcnt(0) -- which drains the DMA ring
-__device__ __forceinline__ uint32_t lds_read_u32(uint32_t addr) {
-  uint32_t v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_write_u32(uint32_t addr, uint32_t v) {
-  asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void post_ticket(uint32_t word, uint32_t v) {
-  if ((threadIdx.x & 63) == 0) lds_write_u32(word, v);
-}
-__device__ __forceinline__ uint32_t take_ticket(uint32_t word) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u32(word));
-}
-
-// ---- one work item of a persistent workgroup -----------------------------------------------------------------------
-// The waves of a workgroup, one tile, frames f0..f1-1; frame i lives in ring slot (i + ph) % K (ph = where the ring
-// stood when the item began).  The frame loop is unrolled over the K slots and ENTERED at slot ph: its counter starts at
-// -ph, so that step S of the unrolled body always works on slot S.
-// Timeline of a wave at frame i:
+// The four waves of a workgroup, one tile, frames f0..f1-1.  P = slot class, K = frames in the ring.
+// Timeline of a wave at frame i (slot i % K):
 //     wait until MY pieces of frame i have landed | BARRIER i | store frame i-1's pixels | refill the slot frame i-1
 //     used with my pieces of frame i+K-1 | gather frame i
-// The store is deferred past the barrier so that the wave's vmcnt stream, which holds its DMA loads AND its stores, has
-// no store younger than the loads it is about to wait for: loads complete in order among themselves, so "at most D
-// operations outstanding", D = my loads younger than frame i's, implies frame i's pieces are done whatever the (older)
-// stores do.
-//
-// A workgroup is PERSISTENT: it walks a list of items, and the ring does not drain between them.  While it gathers the
-// last K-1 frames of an item -- when it has nothing left to stage for it -- it already stages the first K-1 frames of
-// its NEXT item into the slots that fall free (`pre` = frames of this item that the previous item staged).  What that
-// needs of the next tile -- my pieces' chunk entries and the descriptor -- is prefetched by DMA into the LDS area
-// behind the ring at this item's first frame, together with a touch of the next tile's pixel words and row table that
-// pulls them into the L2; so an item change costs the pixel set-up (two L2 round trips: words, then weights), not the
-// ~6 us of a cold start (tables from HBM, then weights, then the first frames).
-template <int NPX, int KS, int GROUP, int WAVES>
-__device__ __forceinline__ int tile_item(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, int b, int f0, int f1, int pre, int ph,
-                                         bool& has_next, Item& nx, uint8_t* __restrict__ lds, int (&goff)[4], int& mine, int xcd,
-                                         uint32_t tbase, int item_no) {
-  using R = Ring<KS, WAVES>;
-  constexpr int K = R::K;
-  const int tid = threadIdx.x, lane = tid & 63;
+// The store is deferred past the barrier so that the wave's vmcnt stream, which now holds its DMA loads AND its
+// stores, has no store younger than the loads it is about to wait for: loads complete in order among themselves, so
+// "at most D operations outstanding", D = my loads younger than frame i's, implies frame i's pieces are done whatever
+// the (older) stores do.
+template <int NPX, int KS, int GROUP, int P, int K, int WAVES>
+__device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane& pl, const TileDesc& t, const TileFetch& tf,
+                                           const uint8_t* __restrict__ lds, int f0, int f1) {
+  constexpr bool DUAL = dual_copy(KS);
+  using R = Slot<P, DUAL>;
+  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nf = f1 - f0;
-#ifdef T360_INSTRUMENT
-  // item timeline (T360_PHASES): wall clock (100 MHz) of wave 0 at the begin of the item, after the ticket, after the
-  // pixel set-up and at the end, for the first four items of the workgroup
-#define T360_ITEM_MARK(k)                                                                                  \
-  if (a.phases && tid == 0 && item_no < 4)                                                                 \
-    a.phases[(size_t)blockIdx.x * 32 + 16 + item_no * 4 + (k)] = (unsigned long long)wall_clock64();
-#else
-#define T360_ITEM_MARK(k)
-#endif
-  T360_ITEM_MARK(0);
-  const uint32_t* __restrict__ tc = pl.chunks + (size_t)b * tile_chunk_dwords(a.max_pieces);
-  // ---- this tile's pixels: words and row table (pulled into the L2 by the previous item), then the weights
-  TileFetch tf;
-  if (KS == 8) {
-    tf.words[0] = tid < 256 ? pl.tlut[(size_t)b * tile_words(KS, WAVES) + tid] : kWordDead;
-    tf.words[1] = tf.words[2] = tf.words[3] = kWordDead;
-  } else {
-    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)b * tile_words(KS, WAVES))[tid];
-    tf.words[0] = v.x; tf.words[1] = v.y; tf.words[2] = v.z; tf.words[3] = v.w;
-  }
-  tf.rowdw = tc[a.max_pieces * kPieceChunks + lane];
-  // The ticket of this workgroup's NEXT item is taken here: one scalar atomic per item and workgroup, by wave 0, which
-  // waits for it -- beside the loads above, which every wave has to wait for anyway -- and hands it to the other waves
-  // through an LDS word and a barrier.
-#ifdef T360_STATIC_ITEMS
-  // A/B: no tickets, workgroup w of an XCD takes the items w, w + wgs_per_xcd, ... (tbase carries the item number)
-  has_next = decode_item(a, xcd, (int)tbase + (item_no + 1) * a.wgs_per_xcd, &nx);
-#else
-  {
-    const uint32_t tword = (uint32_t)(uintptr_t)lds + (uint32_t)(R::kPfBase + R::MAXJ * 256 + 32);
-    if (wave == 0) post_ticket(tword, grab_tickets(a.tickets + xcd, 1u));
-    frame_barrier();
-    has_next = __builtin_amdgcn_readfirstlane((int)decode_item(a, xcd, (int)(take_ticket(tword) - tbase), &nx)) != 0;
-  }
-#endif
-  T360_ITEM_MARK(1);
-  if (pre == 0) {
-    // nobody staged for me: my pieces' chunk entries come from the table itself (first item of the workgroup)
-    mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;  // my pieces: wave, wave + WAVES, ... (0..MAXJ of them)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int j = 3 - k;
-      const int piece = wave + WAVES * j;
-      const uint32_t e = (j < R::MAXJ && piece < a.max_pieces) ? tc[piece * kPieceChunks + lane] : 0u;
-      goff[k] = j < mine ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
-    }
-  }
+  (void)lane;
+  const int mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;  // my pieces: wave, wave + WAVES, ... (0..4 of them)
   // does this wave hold pixels?  (a 256-lane tile in a workgroup of 8 waves: waves 4..7 only move bytes)
   const bool has_px = WAVES == 4 || t.kind == kTileWide128 || wave < 4;
-  // chunk q = lane + 64*piece lives at LDS byte 16*q of the slot; its source (row, 16-byte column) is the plan's
+  // chunk q = lane + 64*piece lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
   // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
+  int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4's order)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int j = 3 - k;
+    const uint32_t e = tf.chunk[j];
+    goff[k] = (j < mine && WAVES * j < P) ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
+  }
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds + (uint32_t)wave * 1024u;
+  auto issue = [&](int f, int slot_bytes) {
+    if (mine <= 0) return;
+    const uint8_t* base = T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)f * pl.src_frame_bytes));
+    dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, WAVES * 1024u, goff);
+    if (DUAL && !T360_DBG(a, 5)) dma_frame_4(mine, base, lds_base + (uint32_t)(slot_bytes + R::kCopyB), WAVES * 1024u, goff);
+  };
+  const int per_frame = DUAL ? 2 * mine : mine;  // my DMA instructions per frame
+  const int nf = f1 - f0;
+  T360_MARK(a, 1);  // tile tables here
+  // weights first (they depend on the pixel words only), then the prologue DMA, then wait for both
   PixelSetup<NPX, KS> px;
-  load_pixels<NPX, KS>(tf, a.wpack, px);
+  load_pixels<NPX, KS, P>(tf, a.wpack, px);
 #pragma unroll
   for (int j = 0; j < K - 1; j++)
-    if (j >= pre && j < nf && mine > 0)
-      dma_frame_4(mine, T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)(f0 + j) * pl.src_frame_bytes)),
-                  lds_base + (uint32_t)(((j + ph) % K) * R::kSlot), WAVES * 1024u, goff);
-  pin_pixels<NPX, KS>(px);  // hipcc's wait for the weights: everything issued so far has landed behind it
-  T360_ITEM_MARK(2);
+    if (j < nf) issue(f0 + j, j * R::kSlot);
+  pin_pixels<NPX, KS>(px);
+  T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
   const uint32_t doff = out_pos<NPX>(pl, t, dword_store);
   uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);  // the store uses SGPR base + VGPR offset
   uint32_t pending = 0;
-  // the next item is staged from inside this one if this one is long enough to hide the prefetch of its tables
-  const int nfn = nx.f1 - nx.f0;
-  const bool pipe = has_next && nf >= K + 1 && nfn >= 1 && !T360_DBG(a, 6);
-  const uint32_t pf = (uint32_t)(uintptr_t)lds + (uint32_t)(R::kPfBase + wave * R::kPfWave);  // my prefetch area
-  int n_pref = 0, mine_n = 0;
-  const uint8_t* src_n = nullptr;  // first frame of the next item in its plane
-  int64_t frame_bytes_n = 0;
-  int sstride_n = 0;
-  if (pipe) {
-    // prefetch the next tile's tables: the chunk entries of my pieces and the descriptor -> LDS, words and row table
-    // -> L2 (a touch per 128-byte line, landing where the chunk entries overwrite it).  These DMA instructions are
-    // younger than the frames 0 .. K-2 and older than every frame staged from the loop below.
-    int bn = nx.b;
-    const int pin = plane_of(a, &bn);
-    const uint32_t* tcn = T360_PLANE_FIELD(a, pin, chunks) + (size_t)bn * tile_chunk_dwords(a.max_pieces);
-    if (wave == 0) {
-      constexpr int nlines = tile_words(KS, WAVES) * 4 / 128;  // <= 64 lines of 128 bytes
-      if (lane < nlines) dma_dword(T360_PLANE_FIELD(a, pin, tlut) + (size_t)bn * tile_words(KS, WAVES), (uint32_t)lane * 128u, pf);
-      n_pref++;
-    }
-    if (wave == WAVES - 1) {
-      if (lane < 2) dma_dword(tcn + a.max_pieces * kPieceChunks, (uint32_t)lane * 128u, pf);
-      n_pref++;
-    }
-#pragma unroll
-    for (int j = 0; j < R::MAXJ; j++) {
-      const int piece = wave + WAVES * j;
-      if (piece < a.max_pieces) {
-        dma_dword(tcn, (uint32_t)(piece * kPieceChunks + lane) * 4u, pf + (uint32_t)j * 256u);
-        n_pref++;
-      }
-    }
-    if (lane < 8) dma_dword(T360_PLANE_FIELD(a, pin, tiles) + bn, (uint32_t)lane * 4u, pf + (uint32_t)R::MAXJ * 256u);
-    n_pref++;
-    sstride_n = T360_PLANE_FIELD(a, pin, sstride);
-    frame_bytes_n = T360_PLANE_FIELD(a, pin, src_frame_bytes);
-    src_n = T360_PLANE_FIELD(a, pin, src) + (size_t)nx.f0 * frame_bytes_n;
-  }
 #ifdef T360_INSTRUMENT
   // phase profile (T360_PHASES=file): shader-clock cycles this wave spent in each part of the frame loop, summed over
   // the frames: [0] waiting for its DMA pieces, [1] at the barrier, [2] store + DMA issue, [3] gather, [4] the rest
   unsigned long long ph_acc[5] = {0, 0, 0, 0, 0}, ph_last = a.phases ? __builtin_readcyclecounter() : 0;
-#define T360_PHASE(k)                                             \
-  if (a.phases) {                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+#define T360_PHASE(k)                                          \
+  if (a.phases) {                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
     const unsigned long long now_ = __builtin_readcyclecounter(); \
-    ph_acc[k] += now_ - ph_last;                                  \
-    ph_last = now_;                                               \
+    ph_acc[k] += now_ - ph_last;                               \
+    ph_last = now_;                                            \
   }
 #else
 #define T360_PHASE(k)
 #endif
-  for (int i = -ph; i < nf; i += K) {
-#define T360_STEP(S)                                                                                                 \
-    if constexpr (S < K) if (i + S >= 0 && i + S < nf) {                                                             \
-      const int q = i + S;                                                                                           \
-      /* my loads younger than frame q's: the frames q+1 .. q+K-2 (this item's or the next one's), and the */       \
-      /* prefetches, which went out behind the frames 0 .. K-2 */                                                    \
-      int allowed = (K > 2 && q >= 1 && q <= K - 2) ? n_pref : 0;                                                    \
-      _Pragma("unroll") for (int m = 1; m <= K - 2; m++)                                                             \
-        allowed += q + m < nf ? mine : (pipe && q + m - nf < nfn ? mine_n : 0);                                      \
-      T360_PHASE(4);                                                                                                 \
-      wait_vmcnt(allowed);                                                                                           \
-      T360_PHASE(0);                                                                                                 \
-      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */               \
-      T360_PHASE(1);                                                                                                 \
-      if (q > 0) {                                                                                                   \
-        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                                    \
-        d += pl.dst_frame_bytes;                                                                                     \
-      }                                                                                                              \
-      if (pipe && q == nf - (K - 1)) {                                                                               \
-        /* from here on the slots that fall free take the NEXT item's frames: its chunk entries replace mine */      \
-        const int pieces_n = __builtin_amdgcn_readfirstlane((int)(lds_read_u32(pf + (uint32_t)(R::MAXJ * 256 + 8)) & 0xffffu)); \
-        mine_n = (pieces_n - wave + WAVES - 1) / WAVES;                                                              \
-        _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                              \
-          const int j = 3 - k;                                                                                       \
-          const uint32_t e = j < R::MAXJ ? lds_read_u32(pf + (uint32_t)(j * 256 + lane * 4)) : 0u;                   \
-          goff[k] = j < mine_n ? (int)(e >> 12) * sstride_n + (int)(e & 4095u) * kStageChunk : 0;                    \
-        }                                                                                                            \
-      }                                                                                                              \
-      if (!T360_DBG(a, 1)) {                                                                                         \
-        const int fi = q + K - 1;                                                                                    \
-        if (fi < nf) {                                                                                               \
-          if (mine > 0)                                                                                              \
-            dma_frame_4(mine, T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)(f0 + fi) * pl.src_frame_bytes)),   \
-                        lds_base + (uint32_t)(((S + K - 1) % K) * R::kSlot), WAVES * 1024u, goff);                   \
-        } else if (pipe && fi - nf < nfn && mine_n > 0) {                                                            \
-          dma_frame_4(mine_n, T360_UNIFORM(const_cast<uint8_t*>(src_n + (size_t)(fi - nf) * frame_bytes_n)),         \
-                      lds_base + (uint32_t)(((S + K - 1) % K) * R::kSlot), WAVES * 1024u, goff);                     \
-        }                                                                                                            \
-      }                                                                                                              \
-      T360_PHASE(2);                                                                                                 \
+  for (int i = 0; i < nf; i += K) {
+#define T360_STEP(S)                                                                                       \
+    if constexpr (S < K) if (i + S < nf) {                                                                 \
+      T360_PHASE(4);                                                                                       \
+      wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
+      T360_PHASE(0);                                                                                       \
+      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
+      T360_PHASE(1);                                                                                       \
+      if (i + S > 0) {                                                                                     \
+        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                          \
+        d += pl.dst_frame_bytes;                                                                           \
+      }                                                                                                    \
+      if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
+      T360_PHASE(2);                                                                                       \
       if (has_px && !T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store); \
-      asm volatile("" : "+v"(pending));                                                                              \
-      T360_PHASE(3);                                                                                                 \
+      asm volatile("" : "+v"(pending));                                                                    \
+      T360_PHASE(3);                                                                                       \
+      if (i + S == 0) T360_MARK(a, 3);                                                                     \
+      if (i + S == 1) T360_MARK(a, 4);                                                                     \
     }
     T360_STEP(0) T360_STEP(1) T360_STEP(2) T360_STEP(3)
 #undef T360_STEP
   }
   if (nf > 0 && has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
-  T360_ITEM_MARK(3);
-#undef T360_ITEM_MARK
 #ifdef T360_INSTRUMENT
   if (a.phases && (wave == 0 || wave == WAVES - 1) && lane == 0) {
-    unsigned long long* o = a.phases + ((size_t)blockIdx.x * 32 + (wave == 0 ? 0 : 8));
+    unsigned long long* o = a.phases + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);
 #pragma unroll
-    for (int k = 0; k < 5; k++) atomicAdd(o + k, ph_acc[k]);
-    atomicAdd(o + 5, (unsigned long long)nf);
+    for (int k = 0; k < 5; k++) o[k] = ph_acc[k];
+    o[5] = (unsigned long long)nf;
     o[6] = ((unsigned long long)(unsigned)t.kind << 32) | (unsigned)t.pieces;
   }
 #endif
 #undef T360_PHASE
-  if (!pipe) return 0;
-  mine = mine_n;  // goff[] already holds the next item's offsets
-  return nfn < K - 1 ? nfn : K - 1;
+  T360_MARK(a, 5);
 }
 
 // ---- tiles too large to stage: direct gather ---------------------------------------------------
@@ -863,27 +691,28 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
   }
 }
 
-
-// Grid (1-D): the direct tiles' work items first (they are the slowest per pixel), then wgs_per_xcd persistent
-// workgroups per XCD (workgroup id runs on XCD id % 8, MI355X_MICROARCH.md "Workgroup dispatch"; direct_blocks is a
-// multiple of 8): workgroup w of an XCD takes the XCD's items w, w + wgs_per_xcd, w + 2 wgs_per_xcd, ...
-template <int KS, int WAVES>
+// Grid (1-D): the direct tiles' work items first (they are the slowest per pixel), then the staged tiles'.
+template <int KS, int RINGKB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void remap_tiled_kernel(TiledArgs a) {
 #ifndef T360_GROUP
 #define T360_GROUP 4
 #endif
   constexpr int GROUP = T360_GROUP;  // pixels whose LDS reads are in flight together (4: one LDS round trip per frame)
-  using R = Ring<KS, WAVES>;
+  constexpr bool DUAL = dual_copy(KS);
   extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
-  int id = blockIdx.x;
+  // Work items = (tile, frame group), numbered with the frame group fastest: the groups of one tile start within
+  // microseconds of each other on the same XCD, so the tile's tables come from HBM once and from L2 afterwards.
+  int id = blockIdx.x, b, g, f0, f1;
+  // pick the plane with scalar selects: indexing a.plane[] with a run-time index would make
+  // hipcc copy the whole argument block to scratch
+  TiledPlane pl = a.plane[0];
   if (id < a.direct_blocks) {
     // direct tiles, one work item per (tile, frame group); consecutive ids run on different XCDs, so the pole tiles --
     // every lane of which pulls whole 128-byte lines of the polar source rows through its XCD's L2 for 4 bytes each --
     // are spread over all eight L2s (concentrated on one XCD per pole they slowed that XCD's staged tiles enough to
     // set the launch's critical path)
-    TiledPlane pl = a.plane[0];
     int t_idx = id / a.groups;
-    const int g = id - t_idx * a.groups;
+    g = id - t_idx * a.groups;
     if (t_idx >= a.total_direct || T360_DBG(a, 2)) return;
     if (a.nplanes > 1 && t_idx >= pl.ndirect) {
       t_idx -= pl.ndirect;
@@ -897,91 +726,145 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         }
       }
     }
-    const int f0 = g * a.frames_per_block;
+    f0 = g * a.frames_per_block;
     direct_tile<KS>(a, pl, pl.tiles[pl.ntiles + t_idx], f0, min(f0 + a.frames_per_block, a.nframes));
     return;
   }
-  id -= a.direct_blocks;
-  const int xcd = id & 7;
-  // (a run-time index into the argument block would make hipcc copy it to scratch: scalar selects)
-  const uint32_t tbase = xcd == 0 ? a.ticket_base[0] : xcd == 1 ? a.ticket_base[1] : xcd == 2 ? a.ticket_base[2] : xcd == 3 ? a.ticket_base[3]
-                       : xcd == 4 ? a.ticket_base[4] : xcd == 5 ? a.ticket_base[5] : xcd == 6 ? a.ticket_base[6] : a.ticket_base[7];
-  Item cur, nx;
-#ifdef T360_STATIC_ITEMS
-  (void)tbase;
-  if (!decode_item(a, xcd, id >> 3, &cur)) return;
-#define tbase ((uint32_t)(id >> 3))
-#else
-  // the first ticket; every later one is taken when the item before it begins (tile_item)
-  const uint32_t tword = (uint32_t)(uintptr_t)lds + (uint32_t)(R::kPfBase + R::MAXJ * 256 + 32);
-  if (threadIdx.x < 64) post_ticket(tword, grab_tickets(a.tickets + xcd, 1u));
-  frame_barrier();
-  if (!decode_item(a, xcd, (int)(take_ticket(tword) - tbase), &cur)) return;
-  frame_barrier();  // everyone has read the word before the first item's ticket overwrites it
-#endif
-  nx = cur;
-  bool has_next = false;
-  int goff[4] = {0, 0, 0, 0};  // goff[k] = source offset of my piece 3-k of the tile being staged (dma_frame_4's order)
-  int mine = 0, pre = 0, ph = 0, item_no = 0;
-  for (;;) {
-    TiledPlane pl;
-    const int b = select_plane(a, cur.b, &pl);
-    const TileDesc t = pl.tiles[b];
-    int pre_next = 0;
-    if (KS == 8 || t.kind == kTileStaged16)
-      pre_next = tile_item<1, KS, GROUP, WAVES>(a, pl, t, b, cur.f0, cur.f1, pre, ph, has_next, nx, lds, goff, mine, xcd, tbase, item_no);
-    else if constexpr (KS != 8)
-      pre_next = tile_item<4, KS, GROUP, WAVES>(a, pl, t, b, cur.f0, cur.f1, pre, ph, has_next, nx, lds, goff, mine, xcd, tbase, item_no);
-    if (!has_next) break;
-    ph = (ph + (cur.f1 - cur.f0)) % R::K;
-    pre = pre_next;
-    cur = nx;
-    item_no++;
+  {
+    // XCD-aware order: workgroup id runs on XCD id % 8 (MI355X_MICROARCH.md "Workgroup dispatch"; direct_blocks is a
+    // multiple of 8); every XCD owns one contiguous range of the execution-ordered tile list, so neighbouring tiles --
+    // whose footprints overlap by the stencil halo -- share an L2
+    id -= a.direct_blocks;
+    const int xcd = id & 7, k = id >> 3;
+    const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+    const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
+    // The last tiles of every XCD's range walk the batch in shorter runs (tail_frames instead of frames_per_block):
+    // the workgroups that finish the launch are then short ones, and the machine drains in ~tail_frames frame times
+    // instead of frames_per_block (a quarter of the grid costs a few extra start-ups, the tail shrinks 4x).
+    const int len_tail = (len * a.tail_percent) / 100, len_head = len - len_tail;
+    int fpb;
+    if (k < len_head * a.groups) {
+      const int t_local = k / a.groups;
+      b = start + t_local;
+      g = k - t_local * a.groups;
+      fpb = a.frames_per_block;
+    } else {
+      const int k2 = k - len_head * a.groups;
+      const int t_local = k2 / a.tail_groups;
+      if (t_local >= len_tail) return;
+      b = start + len_head + t_local;
+      g = k2 - t_local * a.tail_groups;
+      fpb = a.tail_frames;
+    }
+    f0 = g * fpb;
+    f1 = min(f0 + fpb, a.nframes);
   }
-#ifdef T360_STATIC_ITEMS
-#undef tbase
+  if (a.nplanes > 1 && b >= pl.ntiles) {
+    b -= pl.ntiles;
+    pl = a.plane[1];
+    if (a.nplanes > 2 && b >= pl.ntiles) {
+      b -= pl.ntiles;
+      pl = a.plane[2];
+      if (a.nplanes > 3 && b >= pl.ntiles) {
+        b -= pl.ntiles;
+        pl = a.plane[3];
+      }
+    }
+  }
+  const TileFetch tf = fetch_tile<KS, WAVES>(pl, b, a.max_pieces);  // independent of the descriptor: all in flight together
+  const TileDesc t = pl.tiles[b];
+#ifdef T360_INSTRUMENT
+  if (a.trace && threadIdx.x == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const size_t wg = blockIdx.x;
+    a.trace[wg * 8 + 7] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    a.trace[wg * 8 + 6] = ((unsigned long long)(unsigned)t.kind << 32) | (unsigned)t.pieces;
+  }
+  T360_MARK(a, 0);  // tile descriptor here
 #endif
+  if (T360_DBG(a, 3) && t.kind == kTileStaged16) return;
+  if (T360_DBG(a, 4) && t.kind != kTileStaged16) return;
+  const int pieces = (int)t.pieces;
+  if (KS == 8 || t.kind == kTileStaged16) {
+#define T360_TILE1(P) \
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2) tile_waves<1, KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
+    T360_FOR_CLASS(pieces, T360_TILE1)
+#undef T360_TILE1
+  } else {
+#define T360_TILE4(P)                                                        \
+    if constexpr (Cls<RINGKB, P, DUAL>::K >= 2)                               \
+      tile_waves<(KS == 8 ? 1 : 4), KS, GROUP, P, Cls<RINGKB, P, DUAL>::K, WAVES>(a, pl, t, tf, lds, f0, f1);
+    T360_FOR_CLASS(pieces, T360_TILE4)
+#undef T360_TILE4
+  }
 }
 
-template <int KS, int WAVES>
-hipError_t launch_one(const TiledArgs& a, hipStream_t stream) {
-  using R = Ring<KS, WAVES>;
-  constexpr int lds_bytes = R::LDSKB * 1024;
-  if (a.max_pieces > R::P || a.wgs_per_xcd <= 0) return hipErrorInvalidValue;
-  // per device and cheap: not cached (handles may live on several devices of one process)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, WAVES>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((remap_tiled_kernel<KS, WAVES>), dim3(a.direct_blocks + 8 * a.wgs_per_xcd, 1, 1), dim3(64 * WAVES),
+// largest tile (in pieces) the ring of RINGKB KiB can hold two frames of
+template <int RINGKB, bool DUAL>
+constexpr int max_pieces_of() {
+  return Cls<RINGKB, 32, DUAL>::K >= 2   ? 32
+         : Cls<RINGKB, 24, DUAL>::K >= 2 ? 24
+         : Cls<RINGKB, 16, DUAL>::K >= 2 ? 16
+         : Cls<RINGKB, 12, DUAL>::K >= 2 ? 12
+         : Cls<RINGKB, 8, DUAL>::K >= 2  ? 8
+                                         : 0;
+}
+
+template <int KS, int RINGKB, int WAVES>
+hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
+  constexpr int lds_bytes = RINGKB * 1024;
+  if (a.max_pieces > max_pieces_of<RINGKB, dual_copy(KS)>()) return hipErrorInvalidValue;
+  if (lds_bytes > 64 * 1024) {
+    // per device and cheap: not cached (handles may live on several devices of one process)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, RINGKB, WAVES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  const int per_xcd = (a.total_tiles + 7) / 8;
+  const int tail = (per_xcd * a.tail_percent) / 100;
+  const int items = (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;  // >= any XCD's item count
+  hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB, WAVES>), dim3(a.direct_blocks + 8 * items, 1, 1), dim3(64 * WAVES),
                      (size_t)lds_bytes, stream, a);
   return hipGetLastError();
 }
 
 template <int KS>
-hipError_t launch_ks(const TiledArgs& a, hipStream_t stream) {
-  return a.waves == 8 ? launch_one<KS, 8>(a, stream) : launch_one<KS, 4>(a, stream);
+hipError_t launch_ks(const TiledArgs& a, int groups, hipStream_t stream) {
+  if (a.waves == 8) {
+    if (a.ring_kb == 76) return launch_one<KS, 76, 8>(a, groups, stream);  // 2 workgroups of 8 waves per CU
+#ifdef T360_INSTRUMENT
+    if (a.ring_kb == 50) return launch_one<KS, 50, 8>(a, groups, stream);  // 3 workgroups of 8 waves per CU
+#endif
+    return hipErrorInvalidValue;
+  }
+  if (a.ring_kb == 38) return launch_one<KS, 38, 4>(a, groups, stream);  // 4 workgroups of 4 waves per CU
+#ifdef T360_INSTRUMENT
+  if (a.ring_kb == 26) return launch_one<KS, 26, 4>(a, groups, stream);  // 6 workgroups per CU
+  if (a.ring_kb == 31) return launch_one<KS, 31, 4>(a, groups, stream);  // 5 workgroups per CU
+  if (a.ring_kb == 50) return launch_one<KS, 50, 4>(a, groups, stream);  // 3 workgroups per CU
+  if (a.ring_kb == 76) return launch_one<KS, 76, 4>(a, groups, stream);  // 2 workgroups per CU
+#endif
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-const char* remap_tiled_kernel_name(int ks, int waves) {
+const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves) {
   static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d>", ks, waves);
+  snprintf(buf, sizeof(buf), "remap_tiled_kernel<%d, %d, %d>", ks, ring_kb, waves);
   return buf;
 }
 
-int tiled_max_pieces(int ks, int waves) {
-  return ks == 8 ? Ring<8, 4>::P : waves == 8 ? Ring<4, 8>::P : Ring<4, 4>::P;
-}
-int tiled_workgroups_per_cu(int ks, int waves) { return ks == 8 || waves != 8 ? 4 : 2; }
-
 hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream) {
   if (a.total_tiles + a.total_direct <= 0 || a.nframes <= 0) return hipSuccess;
+  const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
   switch (a.ks) {
-    case 1: return launch_ks<1>(a, stream);
-    case 2: return launch_ks<2>(a, stream);
-    case 4: return launch_ks<4>(a, stream);
-    case 8: return a.waves == 4 ? launch_one<8, 4>(a, stream) : hipErrorInvalidValue;
+    case 1: return launch_ks<1>(a, groups, stream);
+    case 2: return launch_ks<2>(a, groups, stream);
+    case 4: return launch_ks<4>(a, groups, stream);
+    case 8: return launch_ks<8>(a, groups, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -171,10 +171,6 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     printf("transform360: no usable HIP device (%s)\n", hipGetErrorString(hipGetLastError()));
     return;
   }
-  {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus >= 8) cus_per_xcd_ = (cus + 7) / 8;
-  }
   if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
     printf("transform360: could not create a HIP stream (%s)\n", hipGetErrorString(hipGetLastError()));
     return;
@@ -189,6 +185,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (hipEventCreateWithFlags(&lp_fork_, hipEventDisableTiming) != hipSuccess) return;
 #ifdef T360_INSTRUMENT
   // tuning switches of the instrumented build (tools/ab.sh); the shipped library reads no environment
+  if (const char* e = getenv("T360_RING_KB")) ring_kb_ = atoi(e);
   if (const char* e = getenv("T360_WAVES")) waves_ = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("T360_MAX_PIECES")) max_pieces_ = atoi(e);
   if (const char* e = getenv("T360_FRAMES_PER_BLOCK")) {
@@ -198,7 +195,6 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_TAIL_PCT")) tail_percent_ = atoi(e);
   if (const char* e = getenv("T360_SMALL_BATCH")) small_batch_ = atoi(e);
   if (const char* e = getenv("T360_TAIL_FRAMES")) tail_frames_ = atoi(e);
-  if (const char* e = getenv("T360_WGS_PER_XCD")) wgs_per_xcd_override_ = atoi(e);
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
@@ -1008,10 +1004,9 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
     fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
     // Lanczos4 plans hold 16x16 tiles only (one pixel per lane, 32 weight dwords each): workgroups of 4 waves
+    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
+    fused.ring_kb = (fused.ks == 8 && waves_ == 8) || small ? 38 : ring_kb_;
     fused.waves = fused.ks == 8 || small ? 4 : waves_;
-    fused.max_pieces = planPieces(fused.ks, fused.waves);
-    fused.wgs_per_xcd = wgs_per_xcd_override_ > 0 ? wgs_per_xcd_override_
-                                                  : std::max(1, cus_per_xcd_ * tiled_workgroups_per_cu(fused.ks, fused.waves));
 #ifdef T360_INSTRUMENT
     fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
 #endif
@@ -1024,40 +1019,40 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.tail_percent = fused.tail_groups > fused.groups ? tail_percent_ : 0;
     fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
 #ifdef T360_INSTRUMENT
-    const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * (size_t)fused.wgs_per_xcd;
+    t360::DeviceBuffer trace;
+    const char* trace_path = getenv("T360_TRACE");
+    const size_t nwg = (size_t)fused.direct_blocks + (size_t)8 * (((fused.total_tiles + 7) / 8) + 1) * std::max(fused.groups, fused.tail_groups);
+    if (trace_path && trace.reserve(nwg * 64) && hipMemsetAsync(trace.as<void>(), 0, nwg * 64, stream_) == hipSuccess)
+      fused.trace = trace.as<unsigned long long>();
     t360::DeviceBuffer phases;
     const char* phases_path = getenv("T360_PHASES");
-    if (phases_path && phases.reserve(nwg * 256) && hipMemsetAsync(phases.as<void>(), 0, nwg * 256, stream_) == hipSuccess)
+    if (phases_path && phases.reserve(nwg * 128) && hipMemsetAsync(phases.as<void>(), 0, nwg * 128, stream_) == hipSuccess)
       fused.phases = phases.as<unsigned long long>();
 #endif
-    // work tickets of the persistent workgroups: 8 counters that are never reset; this launch's tickets start where the
-    // previous launch's ended (every workgroup takes one ticket when it starts and one per item it runs)
-    if (!tickets_.as<void>()) {
-      if (!tickets_.reserve(8 * sizeof(uint32_t)) || !check(hipMemsetAsync(tickets_.as<void>(), 0, 8 * sizeof(uint32_t), stream_), "hipMemset(tickets)"))
-        return false;
-      memset(ticket_base_, 0, sizeof(ticket_base_));
-    }
-    fused.tickets = tickets_.as<uint32_t>();
-    for (int x = 0; x < 8; x++) {
-      fused.ticket_base[x] = ticket_base_[x];
-      const int q = fused.total_tiles >> 3, rem = fused.total_tiles & 7;
-      const int len = q + (x < rem ? 1 : 0), len_tail = (len * fused.tail_percent) / 100, len_head = len - len_tail;
-      ticket_base_[x] += (uint32_t)(len_head * fused.groups + len_tail * fused.tail_groups) + (uint32_t)fused.wgs_per_xcd;
-    }
     const bool ok = check(launch_remap_tiled(fused, stream_), "tiled remap launch");
 #ifdef T360_INSTRUMENT
     if (fused.phases) {
-      std::vector<unsigned long long> host(nwg * 32);
+      std::vector<unsigned long long> host(nwg * 16);
       if (hipStreamSynchronize(stream_) == hipSuccess &&
-          hipMemcpy(host.data(), phases.as<void>(), nwg * 256, hipMemcpyDeviceToHost) == hipSuccess) {
+          hipMemcpy(host.data(), phases.as<void>(), nwg * 128, hipMemcpyDeviceToHost) == hipSuccess) {
         if (FILE* f = fopen(phases_path, "wb")) {
           fwrite(host.data(), 8, host.size(), f);
           fclose(f);
         }
       }
     }
+    if (fused.trace) {
+      std::vector<unsigned long long> host(nwg * 8);
+      if (hipStreamSynchronize(stream_) == hipSuccess &&
+          hipMemcpy(host.data(), trace.as<void>(), nwg * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(trace_path, "wb")) {
+          fwrite(host.data(), 8, host.size(), f);
+          fclose(f);
+        }
+      }
+    }
 #endif
-    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.waves);
+    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.ring_kb, fused.waves);
     reset_fused();
     return ok;
   };
@@ -1174,11 +1169,11 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
     return true;
   };
   const int waves = ks == 8 ? 4 : waves_;
-  if (!build(p.plan, waves, planPieces(ks, waves))) return false;
+  if (!build(p.plan, waves, ks == 8 ? std::min(max_pieces_, 16) : max_pieces_)) return false;
   // Short batches (and the per-plane calls of the reference ABI) run better on workgroups of 4 waves, four to a CU:
   // a workgroup's start-up is then overlapped by three others instead of one (8 frames: 0.049 -> 0.043 ms, 16 frames:
   // 0.076 -> 0.068 ms for BASELINE config 2).  Their tiles are at most 64x16, so they have their own plan.
-  if (waves != 4 && small_batch_ > 0 && !build(p.plan_small, 4, planPieces(ks, 4))) return false;
+  if (waves != 4 && small_batch_ > 0 && !build(p.plan_small, 4, kSmallPlanPieces)) return false;
   return true;
 }
 

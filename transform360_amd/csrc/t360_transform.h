@@ -9,7 +9,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -140,6 +139,7 @@ class VideoFrameTransform {
   // 16 waves, the same as 4 x 4, but half as many tiles' working sets contend for the XCD's L2), up to 24 KiB staged
   // per tile and frame; the ring keeps 3 frames of small tiles, 2 of the largest
   int max_pieces_ = 24;
+  int ring_kb_ = 76;
   int waves_ = 8;
   int frames_per_block_ = 64;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
@@ -147,12 +147,7 @@ class VideoFrameTransform {
                                                // (short workgroups drain the launch; each pays the ~5 us start-up again,
                                                // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
   int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
-  int wgs_per_xcd_override_ = 0;  // instrumented build: persistent workgroups per XCD (tests: few workgroups, long item lists)
-  t360::DeviceBuffer tickets_;  // work counters of the tiled gather's persistent workgroups (t360_remap_tiled.hip)
-  uint32_t ticket_base_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int cus_per_xcd_ = 32;       // compute units of the device / 8 (the persistent workgroups of the tiled gather fill them)
-  // staging budget per tile of the plan for (taps, waves per workgroup): what the kernel instantiation's ring slot holds
-  int planPieces(int ks, int waves) const { return std::min(max_pieces_, t360::tiled_max_pieces(ks, waves)); }
+  static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
   std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
