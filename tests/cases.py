@@ -130,3 +130,40 @@ def case_input(name, in_w, in_h, pad):
     seed = zlib.crc32(name.encode()) | (1 << 33)
     buf = noise_bytes(in_h * (in_w + pad), seed).reshape(in_h, in_w + pad)
     return np.ascontiguousarray(buf)[:, :in_w]
+
+
+# ---- OpenCV pin (tests/golden/make_opencv_fixtures.py, run on any machine that has cv2) ----
+# Small frame cases whose outputs come from REAL OpenCV: every interpolation x both border modes of cv::remap, the
+# fixed-point and the float path of cv::sepFilter2D (segments with real neighbours), cv::resize(INTER_AREA) shrinking
+# by 2x2 / 3x2 / 1.5 and enlarging (factors below 1).  MONO only: the stereo orchestration is the reference's own code
+# and is pinned by oracle/_ref; this file pins the arithmetic underneath.  name -> (overrides, dims)
+def _ocv(interp, **kw):
+    return dict(interpolation_alg=interp, enable_low_pass_filter=0, **kw)
+
+
+OPENCV_CASES = {
+    "ocv_nearest_wrap": (_ocv(NEAREST), (256, 128, 96, 64)),
+    "ocv_linear_wrap": (_ocv(LINEAR), (256, 128, 96, 64)),
+    "ocv_cubic_wrap": (_ocv(CUBIC), (256, 128, 96, 64)),
+    "ocv_lanczos4_wrap": (_ocv(LANCZOS4), (256, 128, 96, 64)),
+    "ocv_cubic_wrap_rotated": (_ocv(CUBIC, fixed_yaw=171, fixed_pitch=80, fixed_roll=13), (320, 160, 192, 128)),
+    "ocv_lanczos4_wrap_rotated": (_ocv(LANCZOS4, fixed_yaw=-179, fixed_pitch=-85), (320, 160, 192, 128)),
+    "ocv_nearest_transparent": (_ocv(NEAREST, output_layout=LAYOUT_BARREL), (256, 128, 160, 64)),
+    "ocv_linear_transparent": (_ocv(LINEAR, output_layout=LAYOUT_BARREL), (256, 128, 160, 64)),
+    "ocv_cubic_transparent": (_ocv(CUBIC, output_layout=LAYOUT_BARREL), (256, 128, 160, 64)),
+    "ocv_lanczos4_transparent": (_ocv(LANCZOS4, output_layout=LAYOUT_BARREL_SPLIT), (256, 128, 96, 64)),
+    # low-pass: integer (Q8 x Q8) path of cv::sepFilter2D -- small symmetric kernels -- and the float path (long ones)
+    "ocv_lpf_fixed_point": (dict(num_vertical_segments=5, num_horizontal_segments=4), (512, 256, 192, 128)),
+    "ocv_lpf_32x15": (dict(num_vertical_segments=15, num_horizontal_segments=32), (960, 480, 192, 128)),
+    "ocv_lpf_float_heavy": (dict(kernel_height_scale_factor=6.0, num_vertical_segments=9, num_horizontal_segments=4),
+                            (512, 256, 96, 64)),
+    "ocv_lpf_noadjust_even": (dict(num_vertical_segments=6, adjust_kernel=0, interpolation_alg=LINEAR), (512, 256, 192, 128)),
+    # supersample + INTER_AREA
+    "ocv_area_2x2": (_ocv(CUBIC, width_scale_factor=2.0, height_scale_factor=2.0), (512, 256, 96, 64)),
+    "ocv_area_3x2": (_ocv(LINEAR, width_scale_factor=3.0, height_scale_factor=2.0), (512, 256, 96, 64)),
+    "ocv_area_1p5": (_ocv(CUBIC, width_scale_factor=1.5, height_scale_factor=1.5), (512, 256, 96, 64)),
+    "ocv_area_0p5": (_ocv(CUBIC, width_scale_factor=0.5, height_scale_factor=0.5), (512, 256, 96, 64)),
+    "ocv_area_0p7x0p4": (_ocv(LINEAR, width_scale_factor=0.7, height_scale_factor=0.4), (512, 256, 96, 64)),
+    "ocv_area_1p3x2p7_transparent": (_ocv(CUBIC, width_scale_factor=1.3, height_scale_factor=2.7, output_layout=LAYOUT_BARREL),
+                                     (512, 256, 160, 64)),
+}
