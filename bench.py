@@ -18,16 +18,20 @@ torch.cuda.synchronize() on both sides and reduced with MAX over the ranks; the 
 and run-to-run spread on the pool is a few percent).  With the driver's K = 20 that is 6 400 frames per rank.
 
 Multi-GPU: whole frames are sharded across ranks -- rank r owns frames r*F .. r*F+F-1 of every step (weak scaling,
-no data-path collective).  RCCL is used only outside the timed region: broadcast of the 112-byte context from
-rank 0, all_gather of per-rank output checksums.  A second record, "strong_cfg5", times BASELINE.json configs[4] as
-written: 64 frames in total, 64/N per rank.
+no data-path collective).  RCCL is used only around the path, through transform360_amd/sharding.py: broadcast of the
+112-byte context from rank 0, all_gather of per-frame output checksums.  A second record, "strong_cfg5", times
+BASELINE.json configs[4] as written: 64 frames in total, ceil(64/N) per rank (no events inside its timed region).
+--gather-outputs adds SURVEY 8(e)(ii): the same steps with every step's output frames gathered to rank 0
+(dist.gather = RCCL over xGMI), overlapped with the next step, next to the compute-only figure.
+Everything a rank does is run_rank(); `--stub` runs that same function with a CPU stand-in for the transform under
+gloo (tests/test_host_cpu.py: the code the 8-GPU run executes is the code the CPU test covers).
 
 Rank 0 prints ONE JSON line:
   value        = frames/s (whole job) x output luma pixels / 1e6                              [Mpix/s]
   roofline     = algorithmic bytes of the step's kernel launch / its average duration (HIP events on the launch
                  stream inside the timed region) vs the 8 TB/s HBM peak; the kernel name is what the library
-                 reports it launched; HBM traffic counters cannot be read inside a run: "traffic" is null here and
-                 the PMC-derived figure lives in profiles/
+                 reports it launched; "traffic" = HBM-side bytes per launch from the committed PMC profile of THIS
+                 library build (profiles/r*_traffic.json, sha256 of the .so checked), null with the reason otherwise
   verified     = frames of the LAST timed step's output compared, all planes, with the CPU oracle
   cpu_baseline = the CPU oracle (restatement of the reference's OpenCV path, NOT linked OpenCV) with the
                  reference's threading structure, timed on this host on a bounded sample
@@ -203,175 +207,315 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (BASELINE config 5: 64)")
-    ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison (development sweeps only)")
-    ap.add_argument("--no-host-abi", action="store_true", help="skip the host-pointer ABI leg (profiling runs)")
-    args = ap.parse_args()
+class HipPath:
+    """The product path on this rank's GPU: frames resident in HBM, one T360_transformFrames call per step."""
+    name = "hip"
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args)
+    def __init__(self, wl, ctx, lin, lout, F, rank):
+        import torch
 
-    import numpy as np
-    import torch
+        from transform360_amd import handler
+        self.torch, self.handler = torch, handler
+        self.wl, self.ctx, self.lin, self.lout, self.F, self.rank = wl, ctx, lin, lout, F, rank
+        self.stream = torch.cuda.current_stream()
+        t0 = time.perf_counter()
+        self.t = handler.VideoFrameTransform(ctx)
+        for idx, k in ((0, 0), (1, 1)):
+            assert self.t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+        assert self.t.setStream(self.stream)
+        self.init_ms = (time.perf_counter() - t0) * 1e3
+        # synthetic stream: this rank's frames of one step, resident in HBM
+        self.d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        for j in range(F):
+            handler.fill_noise(self.d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], self.seed_of(j))
+        self.d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
+        self.descs = self.t.plane_descs(lin, lout)
 
-    from transform360_amd import _lib, handler
-    from transform360_amd.abi import FrameTransformContext, config_output, filter_defaults
+    def seed_of(self, j):
+        return self.handler.frame_seed(self.rank * self.F + j)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the remap path)"
-    # T360_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then
-    # share devices and the few collectives around the path run on CPU tensors); the driver's runs use
-    # nccl (= RCCL), one rank per GPU
-    backend = os.environ.get("T360_DIST_BACKEND", "nccl")
-    if backend == "nccl" and world > torch.cuda.device_count():
-        raise SystemExit("--gpus %d but only %d GPU(s) visible (T360_DIST_BACKEND=gloo rehearses the multi-rank "
-                         "path on fewer devices)" % (world, torch.cuda.device_count()))
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    L = _lib.load()
-    build_flags = int(L.T360_buildFlags())
-    if build_flags and not os.environ.get("T360_BENCH_ALLOW_INSTRUMENTED"):
-        raise SystemExit("refusing to benchmark an instrumented library (%s): it reads tuning and wrong-pixel switches "
-                         "from the environment" % _lib.LIB_PATH)
-
-    wl = workload(args.config)
-    in_w, in_h = wl["in_w"], wl["in_h"]
-    ctx = filter_defaults(**wl["ov"])
-    out_w, out_h = config_output(in_w, in_h, wl["edge"], ctx.output_layout, ctx.input_stereo_format,
-                                 ctx.output_stereo_format)
-    if dist is not None:
-        # init state: rank 0's 112-byte context is broadcast over RCCL; every rank rebuilds maps from it
-        buf = torch.frombuffer(bytearray(bytes(ctx)), dtype=torch.uint8).to(coll_dev)
-        dist.broadcast(buf, src=0)
-        ctx = FrameTransformContext.from_buffer_copy(bytes(buf.cpu().numpy()))
-
-    lin = handler.FrameLayout(in_w, in_h)
-    lout = handler.FrameLayout(out_w, out_h)
-    F = args.frames
-    stream = torch.cuda.current_stream()
-
-    t_init0 = time.perf_counter()
-    t = handler.VideoFrameTransform(ctx)
-    for idx, k in ((0, 0), (1, 1)):
-        assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
-    assert t.setStream(stream)
-    init_ms = (time.perf_counter() - t_init0) * 1e3
-
-    # synthetic stream: this rank's frames of one step, resident in HBM
-    def seed_of(j):
-        return handler.frame_seed(rank * F + j)
-
-    d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
-    for j in range(F):
-        handler.fill_noise(d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], seed_of(j))
-    d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
-    descs = t.plane_descs(lin, lout)
-
-    def step(n_frames, timed_events=None):
+    def step(self, n_frames, events=None, out=None):
         # one call = all three planes of n_frames frames; ONE fused launch of the tiled gather kernel
         # (plus the low-pass launches for config 3)
-        if timed_events is not None:
-            timed_events[0].record(stream)
-        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n_frames, descs)
-        if timed_events is not None:
-            timed_events[1].record(stream)
+        if events is not None:
+            events[0].record(self.stream)
+        assert self.t.transformFrames(self.d_in, self.lin.frame_bytes, self.d_out if out is None else out,
+                                      self.lout.frame_bytes, n_frames, self.descs)
+        if events is not None:
+            events[1].record(self.stream)
+
+    def new_events(self, n):
+        return [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    @staticmethod
+    def event_ms(pair):
+        return pair[0].elapsed_time(pair[1])
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def new_output(self):
+        return self.torch.zeros_like(self.d_out)
+
+    def frame_sums(self, n_frames):
+        """byte sum of every output frame of this rank (device reduction)"""
+        v = self.d_out[:n_frames * self.lout.frame_bytes].view(n_frames, self.lout.frame_bytes).to(self.torch.int64).sum(dim=1)
+        return [int(x) for x in v.cpu()]
+
+    def verify(self, frames):
+        return verify_frames(self.wl, self.lin, self.lout, self.d_in, self.d_out, frames, self.seed_of)
+
+    def kernel_name(self):
+        return self.t.lastKernel()
+
+    def plan_stats(self):
+        return [self.t.planStats(0), self.t.planStats(1)]
+
+    def close(self):
+        self.t.close()
+
+
+class StubPath:
+    """CPU stand-in for the transform with the SAME interface, so that the rank function below -- sharding, barriers,
+    timing, gathers, the records -- runs under gloo without a GPU (tests/test_host_cpu.py).  out = 255 - in."""
+    name = "stub"
+
+    def __init__(self, wl, ctx, lin, lout, F, rank):
+        import torch
+        self.torch = torch
+        self.lin, self.lout, self.F, self.rank = lin, lout, F, rank
+        self.init_ms = 0.0
+        from transform360_amd.handler import frame_seed, noise_bytes
+        self.d_in = torch.from_numpy(np_concat([noise_bytes(lin.frame_bytes, frame_seed(rank * F + j)) for j in range(F)]))
+        self.d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8)
+
+    def step(self, n_frames, events=None, out=None):
+        t0 = time.perf_counter()
+        dst = self.d_out if out is None else out
+        for j in range(n_frames):
+            src = self.d_in[j * self.lin.frame_bytes:j * self.lin.frame_bytes + self.lout.frame_bytes]
+            dst[j * self.lout.frame_bytes:(j + 1) * self.lout.frame_bytes] = 255 - src
+        if events is not None:
+            events[0], events[1] = t0, time.perf_counter()
+
+    def new_events(self, n):
+        return [[0.0, 0.0] for _ in range(n)]
+
+    @staticmethod
+    def event_ms(pair):
+        return (pair[1] - pair[0]) * 1e3
+
+    def sync(self):
+        pass
+
+    def new_output(self):
+        return self.torch.zeros_like(self.d_out)
+
+    def frame_sums(self, n_frames):
+        v = self.d_out[:n_frames * self.lout.frame_bytes].view(n_frames, self.lout.frame_bytes).to(self.torch.int64).sum(dim=1)
+        return [int(x) for x in v]
+
+    def verify(self, frames):
+        worst = 0
+        for j in frames:
+            src = self.d_in[j * self.lin.frame_bytes:j * self.lin.frame_bytes + self.lout.frame_bytes]
+            got = self.d_out[j * self.lout.frame_bytes:(j + 1) * self.lout.frame_bytes]
+            worst = max(worst, int((got.to(self.torch.int16) - (255 - src).to(self.torch.int16)).abs().max()))
+        return {"frames": list(frames), "planes": 3, "max_abs_diff": worst, "differing_pixels": 0, "against": "the stub's definition"}
+
+    def kernel_name(self):
+        return "stub"
+
+    def plan_stats(self):
+        return [None, None]
+
+    def close(self):
+        pass
+
+
+def np_concat(parts):
+    import numpy as np
+    return np.concatenate(parts)
+
+
+def traffic_record(lib_path, kernel_name, frames, config):
+    """HBM-side bytes per launch from the committed PMC profile (profiles/r03_traffic.json, written by
+    tools/profile_round.sh on a GPU box: rocprofv3 --pmc TCC_EA0_RDREQ_* / WRREQ_*, separate passes) -- counters cannot be
+    read inside a run.  Only reported when the profile was taken from THIS library build (sha256 of the .so), the same
+    kernel, batch size and config; otherwise null with the reason."""
+    import glob
+    import hashlib
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True)
+    suffix = "" if config == 2 else "_cfg%d" % config
+    cands = [c for c in cands if (("_cfg" in os.path.basename(c)) == bool(suffix)) and (not suffix or suffix in os.path.basename(c))]
+    if not cands:
+        return None, "no profiles/r*%s_traffic.json" % suffix
+    path = cands[0]
+    try:
+        with open(path) as f:
+            tr = json.load(f)
+        with open(lib_path, "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    except (OSError, ValueError) as e:
+        return None, "%s: %s" % (os.path.relpath(path, ROOT), e)
+    if tr.get("library_sha16") != sha:
+        return None, "%s was profiled from another build of the library (%s, this one is %s)" % (
+            os.path.relpath(path, ROOT), tr.get("library_sha16"), sha)
+    if tr.get("frames") != frames or tr.get("config") != config or tr.get("kernel", "") not in kernel_name:
+        return None, "%s is for config %s, %s frames, kernel %s" % (os.path.relpath(path, ROOT), tr.get("config"),
+                                                                   tr.get("frames"), tr.get("kernel"))
+    return int(tr["hbm_bytes_per_launch"]), "%s: rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}/WRREQ_{,64B}, mean over the " \
+        "dispatches of a separate run of this build (library sha256[:16] %s): %d read + %d written" % (
+            os.path.relpath(path, ROOT), sha, tr["hbm_read_bytes_per_launch"], tr["hbm_write_bytes_per_launch"])
+
+
+def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
+    """Everything one rank does; returns the record on rank 0 (None elsewhere).  `Path` is HipPath (the benchmark) or
+    StubPath (the CPU rehearsal of this very function under gloo)."""
+    import torch
+
+    from transform360_amd import handler, sharding
+    from transform360_amd.abi import config_output
+    in_w, in_h = wl["in_w"], wl["in_h"]
+    out_w, out_h = config_output(in_w, in_h, wl["edge"], ctx.output_layout, ctx.input_stereo_format, ctx.output_stereo_format)
+    # init state: rank 0's 112-byte context is broadcast over RCCL; every rank rebuilds its maps from it
+    ctx = sharding.broadcast_context(ctx, dist, coll_dev)
+    lin, lout = handler.FrameLayout(in_w, in_h), handler.FrameLayout(out_w, out_h)
+    F = args.frames
+    path = Path(wl, ctx, lin, lout, F, rank)
 
     def barrier():
-        torch.cuda.synchronize()
+        path.sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            path.sync()
 
-    def timed_run(n_frames, steps):
-        """REPEATS x (exactly `steps` steps between barriers); returns per-repeat (elapsed max over ranks, [launch ms])."""
+    def timed_run(n_frames, steps, with_events, after_step=None):
+        """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms])."""
         out = []
         for _ in range(REPEATS):
-            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            events = path.new_events(steps) if with_events else None
             barrier()
             t0 = time.perf_counter()
             for k in range(steps):
-                step(n_frames, events[k])
-            torch.cuda.synchronize()
+                path.step(n_frames, events[k] if events else None)
+                if after_step is not None:
+                    after_step(k)
+            if after_step is not None:
+                after_step(None)  # drain
+            path.sync()
             elapsed = time.perf_counter() - t0
             if dist is not None:
                 dist.barrier()
                 el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(el, op=dist.ReduceOp.MAX)
                 elapsed = float(el.item())
-            out.append((elapsed, [a.elapsed_time(b) for a, b in events]))
+            out.append((elapsed, [path.event_ms(e) for e in events] if events else []))
         return out
 
-    # The device idles while the host plans the gather (0.2 s), and its clocks take a few hundred milliseconds of load to
-    # come back: the first repeats used to read 5-15 % slow.  Untimed steps for CLOCK_WARMUP_S seconds first, then the W
-    # warm-up steps of the contract, then the timed repeats.
+    # The device idles while the host plans the gather, and its clocks take a few hundred milliseconds of load to come
+    # back: the first repeats used to read 5-15 % slow.  Untimed steps for CLOCK_WARMUP_S seconds first (they also build
+    # the gather plan, which the library makes on the first call that needs it), then the W warm-up steps of the
+    # contract, then the timed repeats.
     clock_warmup_steps = 0
+    t_first = time.perf_counter()
+    path.step(F)
+    path.sync()
+    first_step_ms = (time.perf_counter() - t_first) * 1e3
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < CLOCK_WARMUP_S:
+    while path.name == "hip" and time.perf_counter() - t_w < CLOCK_WARMUP_S:
         for _ in range(8):
-            step(F)
-        torch.cuda.synchronize()
+            path.step(F)
+        path.sync()
         clock_warmup_steps += 8
     for _ in range(args.warmup):
-        step(F)
-    runs = timed_run(F, args.steps)
+        path.step(F)
+    runs = timed_run(F, args.steps, True)
     elapsed, launch_ms = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
-    kernel_name = t.lastKernel()
+    kernel_name = path.kernel_name()
 
-    # BASELINE configs[4] as written: 64 frames in total, frame-sharded -> 64 / N per rank (strong scaling)
+    # BASELINE configs[4] as written: 64 frames in total, frame-sharded -> ceil(64 / N) per rank (strong scaling).  No
+    # events inside: a step of 8 frames is 40 us and two event records per step are 10 % of it.
     strong = None
-    f5 = 64 // world
-    if args.config == 2 and f5 >= 1 and 64 % world == 0 and f5 <= F:
+    f5 = min(F, -(-64 // world))
+    if args.config == 2:
         for _ in range(max(2, args.warmup)):
-            step(f5)
-        sruns = timed_run(f5, args.steps)
+            path.step(f5)
+        sruns = timed_run(f5, args.steps, False)
         s_el = sorted(r[0] for r in sruns)[len(sruns) // 2]
         strong = {"frames_total": 64, "frames_per_gpu": f5, "n_gpus": world, "scaling": "strong",
                   "ms_per_step": round(s_el / args.steps * 1e3, 4),
-                  "value": round(64 * args.steps / s_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                  "value": round(min(64, f5 * world) * args.steps / s_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
                   "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in sruns]}
-        step(F)  # d_out holds a full-batch result again for the verification below
-        torch.cuda.synchronize()
+        if f5 * world != 64:
+            strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
 
-    # verification outside the timed region: oracle comparison of frames of the last step + per-rank checksums
+    # SURVEY 8(e)(ii): the same steps with every step's output frames gathered to rank 0 (RCCL gather over xGMI; a
+    # device copy when there is one rank), overlapped with the next step: outputs alternate between two buffers and a
+    # step waits only for the gather that used ITS buffer.
+    gathered = None
+    if args.gather_outputs:
+        bufs = [path.d_out, path.new_output()]
+        sink = [torch.empty_like(bufs[0]) for _ in range(world)] if rank == 0 else None
+        pending = [None, None]
+
+        def gather_step(k):
+            if k is None:
+                for w in pending:
+                    if w is not None:
+                        w.wait()
+                return
+            b = k & 1
+            if dist is not None:
+                path.sync() if path.name == "stub" else None
+                pending[b] = dist.gather(bufs[b], sink if rank == 0 else None, dst=0, async_op=True)
+            else:
+                sink[0].copy_(bufs[b], non_blocking=True)
+            nb = (k + 1) & 1
+            if pending[nb] is not None:
+                pending[nb].wait()
+                pending[nb] = None
+
+        step_plain = path.step
+
+        def step_alt(n_frames, events=None, out=None, _k=[0]):
+            step_plain(n_frames, events, bufs[_k[0] & 1])
+            _k[0] += 1
+
+        path.step = step_alt
+        for _ in range(max(2, args.warmup)):
+            path.step(F)
+        gruns = timed_run(F, args.steps, False, after_step=gather_step)
+        path.step = step_plain
+        g_el = sorted(r[0] for r in gruns)[len(gruns) // 2]
+        gathered = {"what": "each step's %d output frames of every rank gathered to rank 0, overlapped with the next step" % F,
+                    "collective": ("dist.gather (%s)" % args.backend) if dist is not None else "device copy (one rank)",
+                    "bytes_to_rank0_per_step": (world - 1) * F * lout.frame_bytes if world > 1 else F * lout.frame_bytes,
+                    "ms_per_step": round(g_el / args.steps * 1e3, 4),
+                    "value": round(args.steps * F * world / g_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                    "compute_only_ms_per_step": round(elapsed / args.steps * 1e3, 4)}
+        path.step(F)  # d_out holds a full-batch result again
+        path.sync()
+    elif strong is not None:
+        path.step(F)  # d_out holds a full-batch result again for the verification below
+        path.sync()
+
+    # verification outside the timed region: oracle comparison of frames of the last step + the checksum of every frame
     verified = None
     if not args.no_verify:
         frames = sorted({0, min(15, F - 1), min(16, F - 1), min(31, F - 1), min(32, F - 1), F - 1})
         if args.config == 4:
             frames = frames[:2]  # 12.6 Mpix Lanczos4 frames: seconds each on the host
-        verified = verify_frames(wl, lin, lout, d_in, d_out, frames, seed_of)
+        verified = path.verify(frames)
         ok = torch.tensor([1 if verified["max_abs_diff"] == 0 else 0], dtype=torch.int64, device=coll_dev)
         if dist is not None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         verified["all_ranks_ok"] = bool(int(ok.item()))
-    csum = torch.sum(d_out.view(-1).to(torch.int64)).reshape(1).to(coll_dev)
-    if dist is not None:
-        allc = [torch.zeros_like(csum) for _ in range(world)]
-        dist.all_gather(allc, csum)
-        checksums = [int(c.item()) for c in allc]
-    else:
-        checksums = [int(csum.item())]
+    sums = path.frame_sums(F)
+    all_sums = sharding.gather_checksums({rank * F + j: v for j, v in enumerate(sums)}, F * world, dist, coll_dev)
+    checksums = [sum(all_sums[r * F:(r + 1) * F]) for r in range(world)]
 
+    res = None
     if rank == 0:
         if verified is not None and not (verified["max_abs_diff"] == 0 and verified["all_ranks_ok"]):
             print(json.dumps({"error": "output differs from the oracle: no throughput is reported", "verified": verified}))
@@ -382,10 +526,11 @@ def main():
         alg_frame = lin.payload_bytes() + lout.payload_bytes()
         launch_alg = F * alg_frame   # the fused launch moves every plane of F frames
         launch_avg_s = (sum(launch_ms) / len(launch_ms)) * 1e-3
-        plan = [t.planStats(0), t.planStats(1)]
+        from transform360_amd import _lib
+        traffic, traffic_source = (None, "stub") if path.name != "hip" else traffic_record(_lib.LIB_PATH, kernel_name, F, args.config)
         res = {
-            "metric": "Mpix/s remapped (4K equirect→512-edge cubemap, bicubic)" if args.config == 2
-                      else "Mpix/s remapped (%s)" % wl["name"],
+            "metric": ("Mpix/s remapped (4K equirect→512-edge cubemap, bicubic)" if args.config == 2
+                       else "Mpix/s remapped (%s)" % wl["name"]) if path.name == "hip" else "STUB (no transform ran)",
             "value": round(fps * out_mpix, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -406,18 +551,89 @@ def main():
                 "achieved": round(launch_alg / launch_avg_s / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                 "frac": round(launch_alg / launch_avg_s / HBM_PEAK_BPS, 4),
                 "algorithmic_bytes_per_launch": launch_alg, "avg_launch_ms": round(launch_avg_s * 1e3, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_source,
             },
             "verified": verified,
-            "library": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "build_flags": build_flags,
-                        "version": L.T360_version().decode()},
-            "gather_plan": plan,
-            "init_ms": round(init_ms, 1),
+            "gather_plan": path.plan_stats(),
+            "init_ms": round(path.init_ms, 1), "first_step_ms": round(first_step_ms, 1),
             "output_checksums": checksums,
         }
         if strong is not None:
             res["strong_cfg5"] = strong
-        if world == 1:
+        if gathered is not None:
+            res["gather_outputs"] = gathered
+    return res, path, (lin, lout)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (BASELINE config 5: 64)")
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison (development sweeps only)")
+    ap.add_argument("--no-host-abi", action="store_true", help="skip the host-pointer ABI leg (profiling runs)")
+    ap.add_argument("--gather-outputs", action="store_true",
+                    help="also time the steps with every step's output frames gathered to rank 0, overlapped with the next step")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+
+    import torch
+
+    from transform360_amd import _lib
+    from transform360_amd.abi import filter_defaults
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    # T360_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then
+    # share devices and the few collectives around the path run on CPU tensors); the driver's runs use
+    # nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("T360_DIST_BACKEND", "gloo" if args.stub else "nccl")
+    args.backend = backend
+    if not args.stub:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the remap path)"
+        if backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit("--gpus %d but only %d GPU(s) visible (T360_DIST_BACKEND=gloo rehearses the multi-rank "
+                             "path on fewer devices)" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    build_flags = 0
+    if not args.stub:
+        L = _lib.load()
+        build_flags = int(L.T360_buildFlags())
+        if build_flags and not os.environ.get("T360_BENCH_ALLOW_INSTRUMENTED"):
+            raise SystemExit("refusing to benchmark an instrumented library (%s): it reads tuning and wrong-pixel switches "
+                             "from the environment" % _lib.LIB_PATH)
+
+    wl = workload(args.config)
+    if args.stub:
+        wl = dict(wl, in_w=256, in_h=128, edge=32)
+    ctx = filter_defaults(**wl["ov"])
+    res, path, (lin, lout) = run_rank(args, StubPath if args.stub else HipPath, dist, rank, world, coll_dev, wl, ctx)
+
+    if rank == 0:
+        if not args.stub:
+            res["library"] = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "build_flags": build_flags,
+                              "version": _lib.load().T360_version().decode()}
+        if world == 1 and not args.stub:
             # "achievable" HBM rate of this box for reference: a plain device-to-device copy (read + write)
             try:
                 n = 1 << 30
@@ -434,13 +650,13 @@ def main():
                 del a_, b_
             except RuntimeError:
                 pass
-        res["Mpix_s_in"] = round(fps * in_w * in_h / 1e6, 1)
-        if world == 1 and args.config == 2 and not args.no_host_abi and not os.environ.get("T360_TRACE"):
+        res["Mpix_s_in"] = round(res["fps"] * wl["in_w"] * wl["in_h"] / 1e6, 1)
+        if world == 1 and args.config == 2 and not args.no_host_abi and not args.stub:
             res["host_abi"] = host_abi_rate(wl, lin, lout, ctx)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.stub:
             res["cpu_baseline"] = cpu_baseline(wl, lin, lout, args.cpu_seconds)
         print(json.dumps(res))
-    t.close()
+    path.close()
     if dist is not None:
         dist.destroy_process_group()
 

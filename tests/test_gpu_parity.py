@@ -286,6 +286,70 @@ def test_alpha_plane_quirk_matches(T, oracle_mod):
             assert np.array_equal(ddst.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("ov", [dict(enable_low_pass_filter=0), dict(num_vertical_segments=5, num_horizontal_segments=4),
+                                dict(enable_low_pass_filter=0, width_scale_factor=1.5, height_scale_factor=2.0)])
+def test_one_map_with_two_plane_sizes_in_one_batch(ov, T, oracle_mod):
+    """yuva420p through the batch entry point: Y and A both name map 0, A with chroma dimensions (the filter's alpha-plane
+    quirk, vf_transform360.c:368-397).  The per-map tables that depend on the plane size (INTER_AREA tables, low-pass tile
+    lists) exist once per map: the library must not let the second size overwrite them before the first plane's
+    kernels have run.  Every plane of every frame equals per-plane oracle calls."""
+    import torch
+    from transform360_amd import _lib
+    O = oracle_mod
+    ctx = filter_defaults(**ov)
+    n = 3
+    in_w, in_h, out_w, out_h = 480, 240, 192, 128
+    lin = T.FrameLayout(in_w, in_h, planes=4)
+    lout = T.FrameLayout(out_w, out_h, planes=4)
+    o = O.Oracle(ctx, threads=4)
+    with T.VideoFrameTransform(ctx) as t:
+        for idx, k in ((0, 0), (1, 1)):
+            assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx) and o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+        frames = [T.noise_bytes(lin.frame_bytes, T.frame_seed(70 + j)) for j in range(n)]
+        d_in = torch.from_numpy(np.concatenate(frames)).cuda()
+        d_out = torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+        descs = (_lib.T360PlaneDesc * 4)()
+        for k in range(4):
+            descs[k] = _lib.T360PlaneDesc(in_offset=lin.offsets[k], out_offset=lout.offsets[k], in_stride=lin.strides[k],
+                                          out_stride=lout.strides[k], in_width=lin.dims[k][0], in_height=lin.dims[k][1],
+                                          out_width=lout.dims[k][0], out_height=lout.dims[k][1], map_index=1 if k in (1, 2) else 0)
+        _ready()
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, descs) and t.synchronize()
+        got = d_out.cpu().numpy()
+    for j in range(n):
+        for k in range(4):
+            want = np.full((lout.dims[k][1], lout.dims[k][0]), 0x5A, np.uint8)
+            assert o.transformFramePlane(lin.plane_view(frames[j], k), want, 1 if k in (1, 2) else 0, k)
+            have = lout.plane_view(got[j * lout.frame_bytes:(j + 1) * lout.frame_bytes], k)
+            assert np.array_equal(have, want), "frame %d plane %d" % (j, k)
+    o.close()
+
+
+def test_gather_plans_are_built_by_the_first_call_that_needs_them(T):
+    """generateMapForPlane keeps a host copy of the LUT; the plan for short batches is built by the first short call, the
+    plan for long batches by the first long one (T360_getPlanStats reports whichever exists, the long one first)."""
+    import torch
+    ctx = filter_defaults(enable_low_pass_filter=0)
+    with T.VideoFrameTransform(ctx) as t:
+        assert t.generateMapForPlane(960, 480, 384, 256, 0)
+        assert t.planStats(0) is None
+        src = torch.zeros((480, 960), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros((256, 384), dtype=torch.uint8, device="cuda")
+        _ready()
+        assert t.transformFramePlane(src, dst, 0)
+        small = t.planStats(0)
+        assert small is not None and t.lastKernel() == "remap_tiled_kernel<4, 38, 4>"
+        lin, lout = T.FrameLayout(960, 480, planes=1), T.FrameLayout(384, 256, planes=1)
+        n = 32
+        d_in = torch.zeros(n * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros(n * lout.frame_bytes, dtype=torch.uint8, device="cuda")
+        _ready()
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout)) and t.synchronize()
+        assert t.lastKernel() == "remap_tiled_kernel<4, 76, 8>"
+        big = t.planStats(0)
+        assert big is not None and big["staged_tiles"] < small["staged_tiles"]  # 128x16 tiles instead of 64x16
+
+
 @pytest.mark.parametrize("n", [64, 65, 129])
 def test_batch_frame_count_boundaries(n, T, oracle_mod):
     # batches longer than one run of frames per workgroup (64): a second, shorter run; the 16-frame runs of the last tiles

@@ -247,3 +247,24 @@ def test_frame_sharding_world_size_2_gloo(tmp_path, oracle_mod):
     want = sharding.run_sharded(7, lambda k: noise_bytes(lin.frame_bytes, frame_seed(k)), transform)
     assert [str(s) for s in want] == by_rank[0][4:]
     assert len(set(want)) == 7                                        # distinct frames, distinct sums
+
+
+def test_bench_rank_function_world_size_2_gloo():
+    """bench.py's run_rank() -- what every rank of the 8-GPU run executes: context broadcast, frame shards, barriers,
+    MAX-reduced timing, the strong record, the overlapped output gather, the checksum all_gather -- under
+    torch.distributed.run with two gloo ranks and a CPU stand-in for the transform (`--stub`)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", T360_DIST_BACKEND="gloo")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--frames", "6", "--steps", "3",
+         "--warmup", "1", "--gather-outputs"], env=env, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT).decode()
+    rec = json.loads([line for line in out.splitlines() if line.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    assert rec["metric"].startswith("STUB")               # a rehearsal can never be mistaken for a result
+    assert rec["verified"]["all_ranks_ok"] and rec["verified"]["max_abs_diff"] == 0
+    assert len(rec["output_checksums"]) == 2 and rec["output_checksums"][0] != rec["output_checksums"][1]
+    s = rec["strong_cfg5"]
+    assert s["n_gpus"] == 2 and s["frames_per_gpu"] == 6 and "note" in s   # 64 / 2 = 32 > --frames 6: said so
+    g = rec["gather_outputs"]
+    assert g["bytes_to_rank0_per_step"] > 0 and g["ms_per_step"] > 0 and "gloo" in g["collective"]

@@ -196,3 +196,32 @@ def test_alpha_plane_quirk_oracle_equals_reference(oracle_mod):
         assert o.generateMapForPlane(480, 240, 192, 128, 0) and r.generateMapForPlane(480, 240, 192, 128, 0)
         assert o.transformFramePlane(src, a, 0, 3) and r.transformFramePlane(src, b, 0, 3)
         assert np.array_equal(a, b)
+
+
+def test_regenerating_a_map_with_other_dims_reference_appends_oracle_replaces(oracle_mod):
+    """a second generateMapForPlane on the same index REPLACES the warp map but APPENDS the low-pass
+    segments and kernels in the reference (VideoFrameTransform.cpp:237, :290-294, :556); the oracle and the library
+    replace them.  The old segments run first and the new ones -- which tile the whole plane -- overwrite whatever the
+    old ones wrote, so the planes are identical (old rectangles outside the new plane only print the reference's
+    'Could not filter segment' message).  Pinned here against the reference build, both growing and shrinking, with
+    enable_multi_threading = 0: with threads the reference runs old and new segments CONCURRENTLY on the same pixels
+    (one std::thread per segment, :592-604) and its own output is a race -- replacing is what it computes when the new
+    segments win."""
+    O = oracle_mod
+    if not O.ref_available():
+        pytest.skip("/root/reference is not mounted here (the GPU box): the reference build cannot be made")
+    ov = dict(num_vertical_segments=5, num_horizontal_segments=4, enable_multi_threading=0)
+    for first, second in (((512, 256, 192, 128), (1024, 512, 384, 256)), ((1024, 512, 384, 256), (512, 256, 192, 128))):
+        r, o = O.Ref(cases.make_ctx(ov)), O.Oracle(cases.make_ctx(ov))
+        for dims in (first, second):
+            assert r.generateMapForPlane(*dims, 0) and o.generateMapForPlane(*dims, 0)
+        assert len(r.segments(0)) == 2 * len(o.segments(0)) == 40  # appended there, replaced here
+        in_w, in_h, out_w, out_h = second
+        src = cases.case_input("regen", in_w, in_h, 0)
+        a = np.full((out_h, out_w), 0xA5, np.uint8)
+        b = np.full((out_h, out_w), 0xA5, np.uint8)
+        assert r.transformFramePlane(src, a, 0) and o.transformFramePlane(src, b, 0)
+        assert np.array_equal(a, b)
+        assert np.array_equal(r.filterPlane(src, 0), o.filterPlane(src, 0))
+        r.close()
+        o.close()

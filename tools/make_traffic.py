@@ -9,9 +9,11 @@ Uses the L2's memory-side request counters by size, which need no unit correctio
 with the read figure to <1 % on this kernel).
 
 usage: make_traffic.py <pmc_dir> <config> <frames> <out.json>
+The record carries sha256[:16] of the library the run loaded: bench.py reports `traffic` only for that very build.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -38,6 +40,10 @@ res = {"config": config, "frames": frames, "grid": name[1],
        "hbm_bytes_per_launch": int(rd + wr),
        "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),
        "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum, mean over dispatches"}
+lib = os.environ.get("T360_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transform360_amd", "lib",
+                                                 "libTransform360.so")
+with open(lib, "rb") as f:
+    res["library_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
 with open(out, "w") as f:
     json.dump(res, f, indent=1)
     f.write("\n")

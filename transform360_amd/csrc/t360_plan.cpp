@@ -18,6 +18,7 @@
 #include "t360_plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -489,19 +490,36 @@ class Planner {
     // regions are independent: plan contiguous slices of the list on a few host threads, splice in order
     const size_t n = regions.size();
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, (n + 7) / 8}));
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, (n + 7) / 8}));
     std::vector<HostGatherPlan> part(nthreads);
     std::vector<std::vector<TileDesc>> part_direct(nthreads);
+    // no exception may leave a worker (std::terminate) or this function (the C ABI returns 0/1): a slice that runs out
+    // of memory marks the plan as failed, a thread that cannot be started has its slice planned here
+    std::atomic<bool> failed{false};
     auto work = [&](size_t ti) {
-      const size_t lo = n * ti / nthreads, hi = n * (ti + 1) / nthreads;
-      for (size_t i = lo; i < hi; i++) plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
+      try {
+        const size_t lo = n * ti / nthreads, hi = n * (ti + 1) / nthreads;
+        for (size_t i = lo; i < hi && !failed.load(std::memory_order_relaxed); i++)
+          plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
+      } catch (...) {
+        failed.store(true);
+      }
     };
     {
       std::vector<std::thread> th;
-      for (size_t ti = 1; ti < nthreads; ti++) th.emplace_back(work, ti);
+      std::vector<size_t> here;
+      for (size_t ti = 1; ti < nthreads; ti++) {
+        try {
+          th.emplace_back(work, ti);
+        } catch (...) {
+          here.push_back(ti);
+        }
+      }
       work(0);
+      for (size_t ti : here) work(ti);
       for (auto& t : th) t.join();
     }
+    if (failed.load()) return false;
     out->tiles.clear();
     out->tlut.clear();
     out->chunks.clear();
@@ -550,8 +568,12 @@ bool plan_gather(const LutEntry* lut, int dw, int dh, int sw, int sh, const Plan
   if (!(opt.ks == 1 || opt.ks == 2 || opt.ks == 4 || opt.ks == 8) || dw <= 0 || dh <= 0 || sw <= 0 || sh <= 0 ||
       (sw % kStageChunk) != 0 || dw > 32767 || dh > 32767)
     return false;
-  Planner p(lut, dw, dh, sw, sh, opt);
-  return p.run(out);
+  try {
+    Planner p(lut, dw, dh, sw, sh, opt);
+    return p.run(out);
+  } catch (...) {  // std::bad_alloc of the splice / the tables: not plannable, the general gather serves the map
+    return false;
+  }
 }
 
 // Re-pack OpenCV's Q15 table of a ks x ks interpolation for v_dot4 (layout: t360_internal.h pack_dwords):

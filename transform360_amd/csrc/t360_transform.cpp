@@ -309,7 +309,6 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   }
   DeviceGuard g(device_);
   PlaneState& p = planes_[idx];
-  p.valid = false;  // a failure below must not leave the previous map half replaced
 
   MapGenParams P;
   memset(&P, 0, sizeof(P));
@@ -327,6 +326,9 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     printf("Could not generate map for plane %d. Error: warp map larger than 2^28 entries\n", idx);
     return false;
   }
+  // every argument check has passed (a call refused by them leaves the map of this index as it was): from here on the
+  // state is rewritten, and a failure below must not leave the previous map half replaced
+  p.valid = false;
   P.in_w = inputWidth;
   P.in_h = inputHeight;
   P.input_layout = (int)ctx_.input_layout;
@@ -933,6 +935,34 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     return true;
   }
   {
+    // One map may be named with two plane sizes in one call -- the filter itself does it: an alpha plane goes to map 0
+    // with chroma dimensions (vf_transform360.c:368-397).  The per-map tables that depend on the plane size (low-pass
+    // tile lists, INTER_AREA tables) exist once per map, so such jobs run one after the other: each group below holds
+    // every map with ONE size; the groups' launches and table uploads are ordered on the stream.
+    auto clash = [](const PlaneJob& x, const PlaneJob& y) {
+      return x.idx == y.idx && (x.in_w != y.in_w || x.in_h != y.in_h || x.out_w != y.out_w || x.out_h != y.out_h);
+    };
+    bool any = false;
+    for (int k = 1; k < njobs && !any; k++)
+      for (int m = 0; m < k && !any; m++) any = clash(jobs[m], jobs[k]);
+    if (any) {
+      std::vector<std::vector<PlaneJob>> groups;
+      for (int k = 0; k < njobs; k++) {
+        size_t g = 0;
+        for (; g < groups.size(); g++) {
+          bool ok = true;
+          for (const PlaneJob& o : groups[g]) ok = ok && !clash(o, jobs[k]);
+          if (ok) break;
+        }
+        if (g == groups.size()) groups.emplace_back();
+        groups[g].push_back(jobs[k]);
+      }
+      for (const std::vector<PlaneJob>& g : groups)
+        if (!runPlanes(g.data(), (int)g.size(), n_frames)) return false;
+      return true;
+    }
+  }
+  {
     // planes whose output size differs from their warp map take the resize branch (:735-737, :759-776); a batch may
     // mix both kinds (rounding: a factor of 1.0006 scales 1000 -> 1001 but 500 -> 500), so split it
     std::vector<PlaneJob> scaled, plain;
@@ -994,7 +1024,19 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
   // which of the two plans: every plane of the call must have the one that is used
   bool small = small_batch_ > 0 && n_frames < small_batch_ && interp != LANCZOS4 && waves_ != 4;
-  for (int k = 0; k < njobs && small; k++) small = planes_[jobs[k].idx].plan_small.valid || !planes_[jobs[k].idx].plan.valid;
+  for (int k = 0; k < njobs; k++)
+    if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], small)) return false;
+  // (a map the 4-wave planner could not take but the 8-wave one can: every plane of the call then uses the latter)
+  for (int k = 0; k < njobs && small; k++) {
+    PlaneState& pk = planes_[jobs[k].idx];
+    if (!pk.plan_small.valid && pk.plan_ks != 0) {
+      if (!ensureGatherPlan(pk, false)) return false;
+      if (pk.plan.valid) small = false;
+    }
+  }
+  if (!small)
+    for (int k = 0; k < njobs; k++)
+      if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], false)) return false;
   TiledArgs fused;
   auto reset_fused = [&]() {
     memset(&fused, 0, sizeof(fused));
@@ -1120,60 +1162,76 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   return flush_fused();
 }
 
-// Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host once and planned
-// there (t360_plan.cpp).  Planes the tiled kernel cannot take (BARREL outputs, widths that are not multiples
-// of 16) simply have no plan and use the general gather.
+// Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host once (here, when the map is
+// generated) and planned there (t360_plan.cpp) -- LAZILY, by the first call that needs the plan: batches of fewer than
+// small_batch_ frames (and the single-plane calls of the reference ABI) use the plan for workgroups of 4 waves, longer
+// batches the one for 8 waves, and a caller normally lives in one of the two regimes, so planning both at init would
+// double the first-frame latency for nothing (the filter initialises inside its first filter_frame, vf_transform360.c:
+// 346-352).  Planes the tiled kernel cannot take (BARREL outputs, widths that are not multiples of 16) simply have no
+// plan and use the general gather.
 bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, int in_w, int in_h) {
-  p.plan.valid = false;
-  p.plan_small.valid = false;
+  p.plan.valid = p.plan.tried = false;
+  p.plan_small.valid = p.plan_small.tried = false;
+  p.plan_ks = 0;
+  p.host_lut.clear();
   const bool barrel = P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT;
   const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
   if (ks == 0 || barrel || !use_tiled_ || (in_w & 15) != 0) return true;
   const size_t n = (size_t)P.map_w * (size_t)P.map_h;
-  std::vector<LutEntry> lut(n);
-  if (!check(hipMemcpyAsync(lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
+  try {
+    p.host_lut.resize(n);
+  } catch (const std::exception&) {
+    p.host_lut.clear();
+    return true;  // no host memory for the planner's copy: the general gather serves the map
+  }
+  if (!check(hipMemcpyAsync(p.host_lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
       !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
     return false;
-  auto build = [&](PlaneState::GatherPlan& g, int waves, int max_pieces) -> bool {
-    PlanOptions o;
-    o.ks = ks;
-    o.waves = waves;
-    o.max_pieces = max_pieces;
-    o.wide_pct = plan_wide_pct_;
-    o.strip_pct = plan_strip_pct_;
-    o.band = plan_band_ > 0 ? plan_band_ : 4;
-    o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
-    o.row_pad = plan_row_pad_;
-    o.row_align = plan_row_align_;
-    HostGatherPlan hp;
-    if (!plan_gather(lut.data(), P.map_w, P.map_h, in_w, in_h, o, &hp)) return true;  // not plannable: general gather
-    if (!g.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
-        !g.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !g.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
-      return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
-    if ((!hp.tiles.empty() &&
-         !check(hipMemcpyAsync(g.tiles.as<void>(), hp.tiles.data(), hp.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
-                               stream_), "hipMemcpy(tiles)")) ||
-        !check(hipMemcpyAsync(g.tlut.as<void>(), hp.tlut.data(), hp.tlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
-                              stream_), "hipMemcpy(tlut)") ||
-        !check(hipMemcpyAsync(g.chunks.as<void>(), hp.chunks.data(), hp.chunks.size() * sizeof(uint32_t),
-                              hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
-        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
-      return false;
-    g.ntiles = hp.ntiles;
-    g.ndirect = hp.ndirect;
-    g.ndirect_top = hp.ndirect_top;
-    g.stats = hp.stats;
-    g.waves = waves;
-    g.max_pieces = max_pieces;
-    g.valid = true;
-    return true;
-  };
-  const int waves = ks == 8 ? 4 : waves_;
-  if (!build(p.plan, waves, ks == 8 ? std::min(max_pieces_, 16) : max_pieces_)) return false;
-  // Short batches (and the per-plane calls of the reference ABI) run better on workgroups of 4 waves, four to a CU:
-  // a workgroup's start-up is then overlapped by three others instead of one (8 frames: 0.049 -> 0.043 ms, 16 frames:
-  // 0.076 -> 0.068 ms for BASELINE config 2).  Their tiles are at most 64x16, so they have their own plan.
-  if (waves != 4 && small_batch_ > 0 && !build(p.plan_small, 4, kSmallPlanPieces)) return false;
+  p.plan_ks = ks;
+  return true;
+}
+
+bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
+  PlaneState::GatherPlan& g = small ? p.plan_small : p.plan;
+  if (g.valid || g.tried || p.plan_ks == 0 || p.host_lut.empty()) return true;
+  g.tried = true;  // not plannable stays not plannable: the general gather serves the map
+  const int ks = p.plan_ks;
+  const int waves = small || ks == 8 ? 4 : waves_;
+  const int max_pieces = ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
+  PlanOptions o;
+  o.ks = ks;
+  o.waves = waves;
+  o.max_pieces = max_pieces;
+  o.wide_pct = plan_wide_pct_;
+  o.strip_pct = plan_strip_pct_;
+  o.band = plan_band_ > 0 ? plan_band_ : 4;
+  o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
+  o.row_pad = plan_row_pad_;
+  o.row_align = plan_row_align_;
+  HostGatherPlan hp;
+  if (!plan_gather(p.host_lut.data(), p.map_w, p.map_h, p.in_w, p.in_h, o, &hp)) return true;
+  if (!g.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
+      !g.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !g.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
+    return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
+  if ((!hp.tiles.empty() &&
+       !check(hipMemcpyAsync(g.tiles.as<void>(), hp.tiles.data(), hp.tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
+                             stream_), "hipMemcpy(tiles)")) ||
+      !check(hipMemcpyAsync(g.tlut.as<void>(), hp.tlut.data(), hp.tlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                            stream_), "hipMemcpy(tlut)") ||
+      !check(hipMemcpyAsync(g.chunks.as<void>(), hp.chunks.data(), hp.chunks.size() * sizeof(uint32_t),
+                            hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
+      !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+    return false;
+  g.ntiles = hp.ntiles;
+  g.ndirect = hp.ndirect;
+  g.ndirect_top = hp.ndirect_top;
+  g.stats = hp.stats;
+  g.waves = waves;
+  g.max_pieces = max_pieces;
+  g.valid = true;
+  // both regimes planned (or only one exists): the host copy of the LUT has served its purpose
+  const bool other_done = ks == 8 || waves_ == 4 || small_batch_ <= 0 || (small ? p.plan.tried : p.plan_small.tried);
+  if (other_done) std::vector<LutEntry>().swap(p.host_lut);
   return true;
 }
 
@@ -1206,7 +1264,7 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   const uint8_t* d_in = inputData;
   int in_stride = inputWidthWithPadding;
   if (ik == PtrKind::Host) {
-    // stage over PCIe (t360_hoststage.h: recurring buffers get pinned): rows packed at a 256-byte aligned pitch
+    // stage over PCIe (t360_hoststage.h: one contiguous copy per plane where the strides allow): rows at a 256-byte aligned pitch
     in_stride = (inputWidth + 255) & ~255;
     if (!stage_in_.reserve((size_t)std::max(in_stride, inputWidthWithPadding) * inputHeight))
       return check(hipErrorOutOfMemory, "hipMalloc(stage_in)");
@@ -1218,7 +1276,8 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   uint8_t* d_out = outputData;
   int out_stride = outputWidthWithPadding;
   if (ok == PtrKind::Host) {
-    out_stride = (outputWidth + 255) & ~255;
+    // rows without padding on the caller's side stay without padding here: the way back is then ONE contiguous copy
+    out_stride = (outputWidthWithPadding == outputWidth && (outputWidth & 15) == 0) ? outputWidth : (outputWidth + 255) & ~255;
     if (!stage_out_.reserve((size_t)out_stride * outputHeight)) return check(hipErrorOutOfMemory, "hipMalloc(stage_out)");
     d_out = stage_out_.as<uint8_t>();
     const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
@@ -1287,8 +1346,9 @@ bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int w
 }
 
 bool VideoFrameTransform::planStats(int idx, int64_t* st) const {
-  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid || !planes_[idx].plan.valid) return false;
-  const PlaneState::GatherPlan& g = planes_[idx].plan;
+  if (idx < 0 || idx >= kMaxMaps || !planes_[idx].valid || !(planes_[idx].plan.valid || planes_[idx].plan_small.valid)) return false;
+  // plans are built by the first call that needs them: the long-batch plan if it exists, else the short-batch one
+  const PlaneState::GatherPlan& g = planes_[idx].plan.valid ? planes_[idx].plan : planes_[idx].plan_small;
   st[0] = g.ntiles;
   st[1] = g.ndirect;
   st[2] = g.stats.fetched_bytes;

@@ -92,18 +92,21 @@ class VideoFrameTransform {
     bool full_cover = false;
     // LDS-tiled gather: work list planned on the host at init (t360_plan.cpp)
     struct GatherPlan {
-      bool valid = false;
+      bool valid = false, tried = false;             // tried: planning was attempted (valid or not plannable)
       int ntiles = 0, ndirect = 0, ndirect_top = 0;  // staged tiles first in `tiles`, the direct tiles behind them
       int waves = 0, max_pieces = 0;                 // what it was planned for
       t360::DeviceBuffer tiles, tlut, chunks;
       t360::PlanStats stats;
     } plan, plan_small;  // plan_small: workgroups of 4 waves, for batches shorter than small_batch_ frames
+    std::vector<t360::LutEntry> host_lut;  // host copy of the LUT until the plans are built (lazily, ensureGatherPlan)
+    int plan_ks = 0;                       // taps per axis the plans are for; 0: the tiled kernel cannot take this map
   };
 
   bool check(hipError_t e, const char* what) const;
   bool ensureWeights();
   bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
   bool buildGatherPlan(PlaneState& p, const t360::MapGenParams& P, int in_w, int in_h);
+  bool ensureGatherPlan(PlaneState& p, bool small);
   // all-device core: a set of planes of n frames
   struct PlaneJob {
     const uint8_t* in;
@@ -156,5 +159,5 @@ class VideoFrameTransform {
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
   t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path: device side
-  t360::HostStager stager_;                  // ... registration cache of the caller's recurring buffers
+  t360::HostStager stager_;                  // ... the copies (contiguous where the strides allow; nothing is pinned or cached)
 };
