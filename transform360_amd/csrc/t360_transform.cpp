@@ -1276,8 +1276,7 @@ bool VideoFrameTransform::transformFramePlane(uint8_t* inputData, uint8_t* outpu
   uint8_t* d_out = outputData;
   int out_stride = outputWidthWithPadding;
   if (ok == PtrKind::Host) {
-    // rows without padding on the caller's side stay without padding here: the way back is then ONE contiguous copy
-    out_stride = (outputWidthWithPadding == outputWidth && (outputWidth & 15) == 0) ? outputWidth : (outputWidth + 255) & ~255;
+    out_stride = (outputWidth + 255) & ~255;
     if (!stage_out_.reserve((size_t)out_stride * outputHeight)) return check(hipErrorOutOfMemory, "hipMalloc(stage_out)");
     d_out = stage_out_.as<uint8_t>();
     const bool barrel = ctx_.output_layout == LAYOUT_BARREL || ctx_.output_layout == LAYOUT_BARREL_SPLIT;
