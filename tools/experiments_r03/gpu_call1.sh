@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 first GPU call: baseline of this box, 8-frame batch, L2 probe, workgroup trace of the 64-frame launch
 set -u
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/gpurun_out/c1
 mkdir -p $O
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/gpurun_out/c12; mkdir -p $O
 export T360_LIB=$R/transform360_amd/lib/libTransform360_instr.so T360_BENCH_ALLOW_INSTRUMENTED=1
 for v in "A:T360_X=0:64" "B:T360_DEBUG=64:64" "C:T360_X=0:8"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 export T360_BENCH_ALLOW_INSTRUMENTED=1
 echo "#### old"; T360_LIB=$R/tools/ab/libT360_old.so $R/tools/sweep.sh "T360_X=0" "T360_DEBUG=1" "T360_DEBUG=2"
 echo "#### new"; T360_LIB=$R/transform360_amd/lib/libTransform360_instr.so $R/tools/sweep.sh "T360_X=0" "T360_DEBUG=1" "T360_DEBUG=2"

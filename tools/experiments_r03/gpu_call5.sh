@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/gpurun_out/c5; mkdir -p $O
 export T360_BENCH_ALLOW_INSTRUMENTED=1
 echo "##### slots3 (default instr)"

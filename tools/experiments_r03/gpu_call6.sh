@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 export T360_BENCH_ALLOW_INSTRUMENTED=1
 for i in 1 2; do
 echo "##### asmread=0"

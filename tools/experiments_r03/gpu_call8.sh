@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/gpurun_out/c8; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -x -q -k "variants or config2 or shipped or batch" > $O/pytest.log 2>&1; tail -15 $O/pytest.log

@@ -40,6 +40,24 @@ res = {"config": config, "frames": frames, "grid": name[1],
        "hbm_bytes_per_launch": int(rd + wr),
        "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),
        "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum, mean over dispatches"}
+# all kernels of a step (config 3: the low-pass launches too): bytes summed over every dispatch / steps
+steps = len(acc[name].get("TCC_EA0_RDREQ_sum", [])) or 1
+tot_rd = tot_wr = 0.0
+per_kernel = {}
+for k, c in acc.items():
+    if "fill_noise" in k[0] or "mapgen" in k[0]:
+        continue
+    g = lambda n: sum(c.get(n, []))  # noqa: E731
+    krd = 32 * g("TCC_EA0_RDREQ_32B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 128 * g("TCC_EA0_RDREQ_128B_sum")
+    kwr = 64 * g("TCC_EA0_WRREQ_64B_sum") + 32 * (g("TCC_EA0_WRREQ_sum") - g("TCC_EA0_WRREQ_64B_sum"))
+    short = re.search(r"(\w+_kernel)", k[0])
+    key = "%s grid %s" % (short.group(1) if short else k[0][:40], k[1])
+    per_kernel[key] = {"read_bytes_per_step": int(krd / steps), "write_bytes_per_step": int(kwr / steps),
+                       "dispatches_per_step": round(len(c.get("TCC_EA0_RDREQ_sum", [])) / steps, 2)}
+    tot_rd += krd
+    tot_wr += kwr
+res["step_bytes_all_kernels"] = int((tot_rd + tot_wr) / steps)
+res["per_kernel"] = per_kernel
 lib = os.environ.get("T360_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transform360_amd", "lib",
                                                  "libTransform360.so")
 with open(lib, "rb") as f:

@@ -1,19 +1,24 @@
 #!/bin/bash
 # tools/profile_round.sh <tag> : the profile set committed under profiles/ for one round.
-#   1. rocprofv3 --kernel-trace --stats of the default bench.py run (config 2)  -> profiles/<tag>_kernel_stats.csv
-#      and of configs 1, 3, 4                                                    -> profiles/<tag>_cfgN_kernel_stats.csv
-#   2. PMC passes (SQ, TCC memory-side; separate runs, --kernel-trace only)      -> profiles/<tag>_pmc_summary.txt
-#   3. HBM bytes per launch from the PMC passes                                  -> profiles/<tag>_traffic.json
-#   4. the plain bench.py line of the same build                                 -> profiles/<tag>_bench_default.json
-# Run on the GPU box:  gpurun -- 'tools/profile_round.sh r02'
+#   1. the plain bench.py line of this build (with --gather-outputs)               -> profiles/<tag>_bench_default.json
+#      and the 8-frame batch (BASELINE configs[4] per GPU of an 8-GPU node)        -> profiles/<tag>_bench_8frames.json
+#   2. rocprofv3 --kernel-trace --stats of the default run (config 2)              -> profiles/<tag>_kernel_stats.csv
+#      of configs 1, 3, 4                                                          -> profiles/<tag>_cfgN_kernel_stats.csv
+#      and of the 8-frame batch                                                    -> profiles/<tag>_8frames_kernel_stats.csv
+#   3. PMC passes (SQ, TCC memory-side; separate runs, --kernel-trace only)        -> profiles/<tag>_pmc_summary.txt
+#      memory-side passes for configs 1, 3, 4 as well                              -> profiles/<tag>_cfgN_pmc_summary.txt
+#   4. HBM bytes per launch from the PMC passes (with the library's sha256)        -> profiles/<tag>[_cfgN]_traffic.json
+# Run on the GPU box:  gpurun -- 'tools/profile_round.sh r03'
 set -u
 TAG=$1
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$R/profiles"
 cd /tmp && export TMPDIR=/tmp
-python "$R/bench.py" > "$OUT/bench_default.log" 2>&1
+python "$R/bench.py" --gather-outputs > "$OUT/bench_default.log" 2>&1
 grep -h "^{\"metric\"" "$OUT/bench_default.log" | tail -1 > "$R/profiles/${TAG}_bench_default.json"
+python "$R/bench.py" --frames 8 --no-cpu-baseline --no-host-abi > "$OUT/bench_8frames.log" 2>&1
+grep -h "^{\"metric\"" "$OUT/bench_8frames.log" | tail -1 > "$R/profiles/${TAG}_bench_8frames.json"
 for CFG in 2 1 3 4; do
   SUF=$([ $CFG = 2 ] && echo "" || echo "_cfg$CFG")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$CFG" -o "$TAG" -- \
@@ -21,9 +26,17 @@ for CFG in 2 1 3 4; do
   cp "$OUT/trace$CFG/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}${SUF}_kernel_stats.csv" 2>/dev/null
   grep -h "^{\"metric\"" "$OUT/trace$CFG.log" | tail -1 > "$R/profiles/${TAG}${SUF}_bench_under_rocprof.json"
 done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace8" -o "$TAG" -- \
+    python "$R/bench.py" --frames 8 --steps 20 --warmup 3 --no-cpu-baseline --no-host-abi --no-verify > "$OUT/trace8.log" 2>&1
+cp "$OUT/trace8/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_8frames_kernel_stats.csv" 2>/dev/null
 cd "$R" && PMC_MEM=1 tools/prof_pmc.sh "$OUT/pmc" --no-verify > /dev/null 2>&1
 cp "$OUT/pmc/summary.txt" "$R/profiles/${TAG}_pmc_summary.txt"
 python tools/make_traffic.py "$OUT/pmc" 2 64 "$R/profiles/${TAG}_traffic.json"
+for CFG in 1 3 4; do
+  PMC_MEM=only tools/prof_pmc.sh "$OUT/pmc_cfg$CFG" --no-verify --config $CFG > /dev/null 2>&1
+  cp "$OUT/pmc_cfg$CFG/summary.txt" "$R/profiles/${TAG}_cfg${CFG}_pmc_summary.txt"
+  python tools/make_traffic.py "$OUT/pmc_cfg$CFG" $CFG 64 "$R/profiles/${TAG}_cfg${CFG}_traffic.json"
+done
 mkdir -p "$R/gpurun_out/profiles" && cp "$R/profiles/${TAG}"* "$R/gpurun_out/profiles/"
 head -4 "$R/profiles/${TAG}_kernel_stats.csv" | cut -c1-200
-cat "$R/profiles/${TAG}_traffic.json"
+cat "$R/profiles/${TAG}_traffic.json" "$R/profiles/${TAG}_cfg3_traffic.json"
