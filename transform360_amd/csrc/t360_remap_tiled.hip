@@ -299,7 +299,16 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) d[r][k] = *reinterpret_cast<const uint32_t*>(lds + s.addr[0][4 * h + r] + SLOT + 4 * k);
+        for (int k = 0; k < 3; k++) {
+          if (T360_ASMREAD) {
+            // the ring slot as the immediate offset of ds_read_b32 (see the bicubic branch below)
+            const uint32_t la = (uint32_t)(uintptr_t)lds + s.addr[0][4 * h + r];
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d[r][k]) : "v"(la), "n"(SLOT + 4 * k));
+          } else {
+            d[r][k] = *reinterpret_cast<const uint32_t*>(lds + s.addr[0][4 * h + r] + SLOT + 4 * k);
+          }
+        }
+      if (T360_ASMREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count asm loads
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
