@@ -126,8 +126,41 @@ def cpu_baseline(wl, lin, lout, budget_s):
     except OSError:
         pass
     mpix = lout.dims[0][0] * lout.dims[0][1] / 1e6
+    o.close()
+    # The other way to use a host: one single-threaded stream per core, frames independent (what the GPU sharding does
+    # across devices).  Reported next to the reference's own per-frame threading, not instead of it.
+    import threading
+    streams = max(1, min(T, 256))
+    per_stream = [0] * streams
+
+    def stream(i):
+        oi = O.Oracle(ctx, threads=1)
+        for idx, k in ((0, 0), (1, 1)):
+            assert oi.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+        oo = [np.zeros((h, w), np.uint8) for (w, h) in lout.dims]
+        ready.wait()
+        while time.perf_counter() < stop_at[0]:
+            for p in range(3):
+                assert oi.transformFramePlane(lin.plane_view(frame, p), oo[p], 1 if p else 0, p)
+            per_stream[i] += 1
+        oi.close()
+
+    ready, stop_at = threading.Event(), [0.0]
+    ths = [threading.Thread(target=stream, args=(i,)) for i in range(streams)]
+    for th in ths:
+        th.start()
+    t_s = time.perf_counter()
+    stop_at[0] = t_s + max(1.5, budget_s / 5)
+    ready.set()
+    for th in ths:
+        th.join()
+    el_s = time.perf_counter() - t_s
+    frame_parallel = {"value": round(sum(per_stream) / el_s * mpix, 1), "unit": "Mpix/s", "streams": streams,
+                      "frames": sum(per_stream), "seconds": round(el_s, 2),
+                      "what": "one single-threaded oracle per logical core, every stream its own frames (ctypes releases the GIL)"}
     return {
         "value": round(fps * mpix, 3), "unit": "Mpix/s", "cores": best_t, "kind": "port",
+        "frame_parallel_streams": frame_parallel,
         "sample": "%d frames of the same workload in %.1f s on %d threads, the best of a thread sweep %s on a host "
                   "with %d logical cores (oracle = restatement of the reference's OpenCV path, not linked OpenCV); "
                   "map init %.2f s" % (n, el, best_t,

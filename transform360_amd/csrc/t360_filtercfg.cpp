@@ -11,6 +11,11 @@
 // (8-bit fixed-point path iff both kernels are SMOOTH|SYMMETRICAL),
 // producing the packed tap arrays the HIP low-pass kernel consumes.
 //
+// Attribution: the float expressions of Builder::band and effective_ratio below follow, operation by operation, the
+// functions listed above of facebook/transform360 (Copyright (c) 2015-present, Facebook, Inc., BSD license, see that
+// project's LICENSE file): segment kernels have to come out identical to the float bit, and there is one way to get
+// there.  Data structures, classification and packing are this library's own.
+//
 // The reference is C++ with `using namespace std`; calls with float arguments bind to the float
 // overloads (cos(angle) is cosf) and mixed expressions promote to double -- both are spelled
 // out below.  Built with -ffp-contract=off.

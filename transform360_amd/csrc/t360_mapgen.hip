@@ -15,6 +15,11 @@
 // off-centre projection.  The sinf/cosf/tan values of the EQUIRECT / BARREL* / EAC_32 outputs
 // depend on the pixel's column or row only and come from host-evaluated tables
 // (MapGenParams::col_tab / row_tab), so they are the host libm's values by construction.
+// Attribution: the per-pixel float expressions follow, in the reference's evaluation order, transformPos /
+// transformInputPos of facebook/transform360 (VideoFrameTransform.cpp:863-1316; Copyright (c) 2015-present, Facebook,
+// Inc., BSD license, see that project's LICENSE file) -- bit-identical warp maps leave no freedom in the arithmetic.
+// The organisation (face tables instead of switches, host-tabulated transcendentals, one lane per pixel) is this
+// library's own.
 #include <hip/hip_runtime.h>
 
 #include "t360_internal.h"
