@@ -251,6 +251,8 @@ class HipPath:
         self.torch, self.handler = torch, handler
         self.wl, self.ctx, self.lin, self.lout, self.F, self.rank = wl, ctx, lin, lout, F, rank
         self.stream = torch.cuda.current_stream()
+        torch.zeros(1, device="cuda")  # the HIP runtime's own start-up (100+ ms, once per process) is not map generation
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         self.t = handler.VideoFrameTransform(ctx)
         for idx, k in ((0, 0), (1, 1)):
