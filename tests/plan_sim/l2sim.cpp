@@ -136,7 +136,7 @@ extern "C" long long t360_l2replay(const t360::LutEntry* lut_y, int dwy, int dhy
 // plans: luma + chroma.  Returns fabric read lines; out[0..7] = stats
 extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc,
                                 int dhc, int swc, int shc, int ks, int max_pieces, int waves, int order, int nframes, int slots,
-                                int l2_bytes, int ways, int jitter, int fpb, int lead, long long* out) {
+                                int l2_bytes, int ways, int jitter, int fpb, int lead, int spread, int window, long long* out) {
   using namespace t360;
   HostGatherPlan plan[2];
   for (int k = 0; k < 2; k++) {
@@ -168,13 +168,22 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     }
   }
   const int total = (int)tiles.size();
+  std::vector<std::vector<int>> neigh((size_t)total);
+  for (int i = 0; i < total; i++)
+    for (int j = 0; j < total; j++) {
+      if (i == j || tiles[(size_t)i].plane != tiles[(size_t)j].plane) continue;
+      const SimTile &a = tiles[(size_t)i], &b = tiles[(size_t)j];
+      const bool xo = a.ox < b.ox + b.w && b.ox < a.ox + a.w, yo = a.oy < b.oy + b.h && b.oy < a.oy + a.h;
+      const bool xt = a.ox == b.ox + b.w || b.ox == a.ox + a.w, yt = a.oy == b.oy + b.h || b.oy == a.oy + a.h;
+      if ((xo && yt) || (yo && xt)) neigh[(size_t)i].push_back(j);
+    }
   const long long ybytes = (long long)swy * shy, cbytes = (long long)swc * shc;
   const long long frame_in = ybytes + 2 * cbytes;
   const long long oy_bytes = (long long)dwy * dhy, oc_bytes = (long long)dwc * dhc;
   const long long frame_out = oy_bytes + 2 * oc_bytes;
   const uint64_t out_base = (uint64_t)1 << 40;
   long long misses = 0, hits = 0, wr_lines = 0;
-  double tend = 0;
+  double tend = 0, waited = 0;
   std::mt19937 rng(12345);
   for (int xcd = 0; xcd < 8; xcd++) {
     const int q = total >> 3, rem = total & 7;
@@ -199,7 +208,11 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     // `jitter` % of uniform noise; `lead` > 0: a workgroup may not run more than `lead` frames ahead of the slowest
     // resident workgroup of its XCD (it polls every 0.2 us)
     std::vector<double> tnext((size_t)slots, 0.0);
+    std::vector<double> speed((size_t)slots, 1.0);  // per work item: this much slower or faster for its whole life
     const double ta = 0.69, tb = 0.0234;
+    // neighbour-relative limit (lead >= 100: lead - 100 frames): a workgroup may not run more than that many frames
+    // ahead of the slowest RESIDENT workgroup whose tile touches its own
+    std::vector<int> where((size_t)total, -1);  // tile -> slot it is resident in
     std::uniform_real_distribution<double> uni(-1.0, 1.0);
     for (;;) {
       int si = -1;
@@ -212,7 +225,10 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       if (si < 0) break;
       Slot& s = slot[(size_t)si];
       if (s.tile < 0 || s.f >= s.f1) {
+        if (s.tile >= 0) where[(size_t)s.tile] = -1;
         s.tile = items[next].tile; s.f = items[next].f0; s.f1 = items[next].f1; next++;
+        where[(size_t)s.tile] = si;
+        speed[(size_t)si] = 1.0 + 0.01 * spread * uni(rng);
         tnext[(size_t)si] += startup;  // start-up
         s.rot = 0;
         if (lead < 0) {  // start at the frame the XCD's front is on (+ what it will advance during my start-up), wrap around
@@ -221,7 +237,16 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
         s.done = 0;
         continue;
       }
-      if (lead > 0) {
+      if (lead >= 100) {
+        int slowest = 1 << 30;
+        for (int nb : neigh[(size_t)s.tile]) {
+          const int sj = where[(size_t)nb];
+          // a neighbour hopelessly far behind (another generation) is not waited for: nothing to share with it
+          if (sj >= 0 && slot[(size_t)sj].tile == nb && slot[(size_t)sj].f < slot[(size_t)sj].f1 && s.f - slot[(size_t)sj].f <= window)
+            slowest = std::min(slowest, slot[(size_t)sj].f);
+        }
+        if (s.f > slowest + (lead - 100)) { tnext[(size_t)si] += 0.2; waited += 0.2; continue; }
+      } else if (lead > 0) {
         int slowest = 1 << 30;
         for (int i = 0; i < slots; i++)
           if (slot[(size_t)i].tile >= 0 && slot[(size_t)i].f < slot[(size_t)i].f1)
@@ -248,7 +273,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       s.f++;
       s.done++;
       const double pieces = (double)t.chunks.size() / 64.0;
-      tnext[(size_t)si] += (ta + tb * pieces) * (1.0 + 0.01 * jitter * uni(rng));
+      tnext[(size_t)si] += (ta + tb * pieces) * speed[(size_t)si] * (1.0 + 0.01 * jitter * uni(rng));
       tend = std::max(tend, tnext[(size_t)si]);
     }
     misses += l2.miss;
@@ -261,5 +286,6 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
   out[4] = frame_in;
   out[5] = wr_lines;
   out[6] = (long long)(tend * 1000);
+  out[7] = (long long)waited;
   return misses;
 }
