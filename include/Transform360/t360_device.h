@@ -84,8 +84,8 @@ int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i
 
 /* Name of the gather kernel the most recent transform call of this handle launched, e.g.
  * "remap_tiled_kernel<4, 76, 8>" (taps per axis, KiB of LDS per workgroup, waves per workgroup; batches of fewer than 24
- * frames and single-plane calls run "<4, 38, 4>") or "remap_gather_kernel"; "" before the first call.  The pointer is
- * valid until the next transform call on the handle (copy the string to keep it). */
+ * frames and single-plane calls run "<4, 38, 4>") or "remap_gather_kernel"; "" before the first call.  The pointer
+ * stays valid as long as the handle; the characters behind it change with the next transform call. */
 const char* T360_lastKernel(VideoFrameTransform* transform);
 /* Gather plan of `map_index` (the one long batches use): stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
  * by the staged tiles, bytes of LDS filled per frame (one copy), pixels in direct tiles, bytes of the tile

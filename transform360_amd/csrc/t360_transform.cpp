@@ -1094,7 +1094,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       }
     }
 #endif
-    last_kernel_ = remap_tiled_kernel_name(fused.ks, fused.ring_kb, fused.waves);
+    setLastKernel(remap_tiled_kernel_name(fused.ks, fused.ring_kb, fused.waves));
     reset_fused();
     return ok;
   };
@@ -1157,7 +1157,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     a.interp = interp;
     a.border = barrel ? kBorderTransparent : kBorderWrap;  // :716-719
     if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
-    last_kernel_ = "remap_gather_kernel";
+    setLastKernel("remap_gather_kernel");
   }
   return flush_fused();
 }

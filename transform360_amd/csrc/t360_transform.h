@@ -60,7 +60,7 @@ class VideoFrameTransform {
   int segmentCount(int idx) const;
   bool getSegment(int idx, int i, int* rect4, int* lens2, int* fixed_point) const;
   bool copySegmentKernels(int idx, int i, float* kx, float* ky) const;
-  const char* lastKernel() const { return last_kernel_.c_str(); }
+  const char* lastKernel() const { return last_kernel_; }
   bool planStats(int idx, int64_t* stats8) const;
 
  private:
@@ -153,7 +153,8 @@ class VideoFrameTransform {
   static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   bool use_tiled_ = true;
-  std::string last_kernel_;    // gather kernel of the most recent launch (reporting)
+  char last_kernel_[64] = "";  // gather kernel of the most recent launch (reporting); the buffer lives as long as the handle
+  void setLastKernel(const char* name) { snprintf(last_kernel_, sizeof(last_kernel_), "%s", name); }
   bool use_fast_lowpass_ = true;
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
   t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
