@@ -22,7 +22,8 @@ no data-path collective).  RCCL is used only around the path, through transform3
 112-byte context from rank 0, all_gather of per-frame output checksums.  A second record, "strong_cfg5", times
 BASELINE.json configs[4] as written: 64 frames in total, ceil(64/N) per rank (no events inside its timed region).
 --gather-outputs adds SURVEY 8(e)(ii): the same steps with every step's output frames gathered to rank 0
-(dist.gather = RCCL over xGMI), overlapped with the next step, next to the compute-only figure.
+(dist.gather = RCCL over xGMI), overlapped with the next step, next to the compute-only figure; --scatter-inputs adds
+8(e)(iii): the inputs of the next step scattered from rank 0 as well.
 Everything a rank does is run_rank(); `--stub` runs that same function with a CPU stand-in for the transform under
 gloo (tests/test_host_cpu.py: the code the 8-GPU run executes is the code the CPU test covers).
 
@@ -269,13 +270,13 @@ class HipPath:
     def seed_of(self, j):
         return self.handler.frame_seed(self.rank * self.F + j)
 
-    def step(self, n_frames, events=None, out=None):
+    def step(self, n_frames, events=None, out=None, inp=None):
         # one call = all three planes of n_frames frames; ONE fused launch of the tiled gather kernel
         # (plus the low-pass launches for config 3)
         if events is not None:
             events[0].record(self.stream)
-        assert self.t.transformFrames(self.d_in, self.lin.frame_bytes, self.d_out if out is None else out,
-                                      self.lout.frame_bytes, n_frames, self.descs)
+        assert self.t.transformFrames(self.d_in if inp is None else inp, self.lin.frame_bytes,
+                                      self.d_out if out is None else out, self.lout.frame_bytes, n_frames, self.descs)
         if events is not None:
             events[1].record(self.stream)
 
@@ -291,6 +292,16 @@ class HipPath:
 
     def new_output(self):
         return self.torch.zeros_like(self.d_out)
+
+    def new_input(self):
+        return self.d_in.clone()
+
+    def frames_of_rank(self, r):
+        """the F input frames rank r owns, generated here (rank 0 of the scatter variant holds every rank's frames)"""
+        buf = self.torch.empty_like(self.d_in)
+        for j in range(self.F):
+            self.handler.fill_noise(buf[j * self.lin.frame_bytes:(j + 1) * self.lin.frame_bytes], self.handler.frame_seed(r * self.F + j))
+        return buf
 
     def frame_sums(self, n_frames):
         """byte sum of every output frame of this rank (device reduction)"""
@@ -324,11 +335,12 @@ class StubPath:
         self.d_in = torch.from_numpy(np_concat([noise_bytes(lin.frame_bytes, frame_seed(rank * F + j)) for j in range(F)]))
         self.d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8)
 
-    def step(self, n_frames, events=None, out=None):
+    def step(self, n_frames, events=None, out=None, inp=None):
         t0 = time.perf_counter()
         dst = self.d_out if out is None else out
+        d_in = self.d_in if inp is None else inp
         for j in range(n_frames):
-            src = self.d_in[j * self.lin.frame_bytes:j * self.lin.frame_bytes + self.lout.frame_bytes]
+            src = d_in[j * self.lin.frame_bytes:j * self.lin.frame_bytes + self.lout.frame_bytes]
             dst[j * self.lout.frame_bytes:(j + 1) * self.lout.frame_bytes] = 255 - src
         if events is not None:
             events[0], events[1] = t0, time.perf_counter()
@@ -345,6 +357,13 @@ class StubPath:
 
     def new_output(self):
         return self.torch.zeros_like(self.d_out)
+
+    def new_input(self):
+        return self.d_in.clone()
+
+    def frames_of_rank(self, r):
+        from transform360_amd.handler import frame_seed, noise_bytes
+        return self.torch.from_numpy(np_concat([noise_bytes(self.lin.frame_bytes, frame_seed(r * self.F + j)) for j in range(self.F)]))
 
     def frame_sums(self, n_frames):
         v = self.d_out[:n_frames * self.lout.frame_bytes].view(n_frames, self.lout.frame_bytes).to(self.torch.int64).sum(dim=1)
@@ -535,6 +554,58 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         path.step(F)  # d_out holds a full-batch result again for the verification below
         path.sync()
 
+    # the stream originates on rank 0 -- every step's input frames are scattered from rank 0
+    # (RCCL scatter over xGMI; a device copy when there is one rank) into the buffer the NEXT step reads, while the
+    # current step computes, and the outputs are gathered back as above.  Bound by rank 0's links: 7 x 153 GB/s.
+    scattered = None
+    if args.scatter_inputs:
+        ins = [path.d_in, path.new_input()]
+        outs = [path.d_out, path.new_output()]
+        src_all = [path.frames_of_rank(r) for r in range(world)] if rank == 0 else None   # rank 0 holds every rank's frames
+        sink = [torch.empty_like(outs[0]) for _ in range(world)] if rank == 0 else None
+        pend_in, pend_out = [None, None], [None, None]
+
+        def move_step(k):
+            if k is None:
+                for w in pend_in + pend_out:
+                    if w is not None:
+                        w.wait()
+                return
+            b, nb = k & 1, (k + 1) & 1
+            if dist is not None:
+                pend_out[b] = dist.gather(outs[b], sink if rank == 0 else None, dst=0, async_op=True)
+                pend_in[nb] = dist.scatter(ins[nb], src_all if rank == 0 else None, src=0, async_op=True)
+            else:
+                sink[0].copy_(outs[b], non_blocking=True)
+                ins[nb].copy_(src_all[0], non_blocking=True)
+            for q in (pend_out, pend_in):      # the next step reads ins[nb] and writes outs[nb]
+                if q[nb] is not None:
+                    q[nb].wait()
+                    q[nb] = None
+
+        step_plain = path.step
+
+        def step_alt(n_frames, events=None, out=None, inp=None, _k=[0]):
+            step_plain(n_frames, events, outs[_k[0] & 1], ins[_k[0] & 1])
+            _k[0] += 1
+
+        path.step = step_alt
+        for _ in range(max(2, args.warmup)):
+            path.step(F)
+        xruns = timed_run(F, args.steps, False, after_step=move_step)
+        path.step = step_plain
+        x_el = sorted(r[0] for r in xruns)[len(xruns) // 2]
+        scattered = {"what": "each step's %d input frames per rank scattered from rank 0 into the next step's buffer and its "
+                             "output frames gathered to rank 0, both overlapped with the computing step" % F,
+                     "collective": ("dist.scatter + dist.gather (%s)" % args.backend) if dist is not None else "device copies (one rank)",
+                     "bytes_from_rank0_per_step": (world - 1 if world > 1 else 1) * F * lin.frame_bytes,
+                     "bytes_to_rank0_per_step": (world - 1 if world > 1 else 1) * F * lout.frame_bytes,
+                     "ms_per_step": round(x_el / args.steps * 1e3, 4),
+                     "value": round(args.steps * F * world / x_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                     "compute_only_ms_per_step": round(elapsed / args.steps * 1e3, 4)}
+        path.step(F)
+        path.sync()
+
     # verification outside the timed region: oracle comparison of frames of the last step + the checksum of every frame
     verified = None
     if not args.no_verify:
@@ -597,6 +668,8 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             res["strong_cfg5"] = strong
         if gathered is not None:
             res["gather_outputs"] = gathered
+        if scattered is not None:
+            res["scatter_gather"] = scattered
     return res, path, (lin, lout)
 
 
@@ -613,6 +686,8 @@ def main():
     ap.add_argument("--no-host-abi", action="store_true", help="skip the host-pointer ABI leg (profiling runs)")
     ap.add_argument("--gather-outputs", action="store_true",
                     help="also time the steps with every step's output frames gathered to rank 0, overlapped with the next step")
+    ap.add_argument("--scatter-inputs", action="store_true",
+                    help="also time the steps with the inputs scattered from rank 0 and the outputs gathered to it, overlapped")
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
     args = ap.parse_args()

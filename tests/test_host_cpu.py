@@ -258,7 +258,7 @@ def test_bench_rank_function_world_size_2_gloo():
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
          "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--frames", "6", "--steps", "3",
-         "--warmup", "1", "--gather-outputs"], env=env, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT).decode()
+         "--warmup", "1", "--gather-outputs", "--scatter-inputs"], env=env, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT).decode()
     rec = json.loads([line for line in out.splitlines() if line.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
     assert rec["metric"].startswith("STUB")               # a rehearsal can never be mistaken for a result
@@ -268,3 +268,5 @@ def test_bench_rank_function_world_size_2_gloo():
     assert s["n_gpus"] == 2 and s["frames_per_gpu"] == 6 and "note" in s   # 64 / 2 = 32 > --frames 6: said so
     g = rec["gather_outputs"]
     assert g["bytes_to_rank0_per_step"] > 0 and g["ms_per_step"] > 0 and "gloo" in g["collective"]
+    x = rec["scatter_gather"]
+    assert x["bytes_from_rank0_per_step"] > x["bytes_to_rank0_per_step"] > 0 and x["ms_per_step"] > 0
