@@ -719,3 +719,32 @@ def test_handle_churn_does_not_leak_device_memory(T):
     cycle(25)
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 25 handle lifetimes" % ((free0 - free1) >> 20)
+
+
+def test_native_multi_gpu_driver_matches_the_python_path(T):
+    """examples/t360_multi_gpu.cpp (C++, links -lTransform360 -lrccl: one thread + handle + stream per device) on the
+    devices of this box: its output checksum for device 0 equals the sum of the bytes the ctypes path produces for the
+    same synthetic frames."""
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "t360_multi_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("examples/t360_multi_gpu not built (make -C examples; __graft_entry__.build() does it)")
+    F = 5
+    out = subprocess.run([exe, "--devices", "1", "--frames", str(F), "--steps", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = int(out.stdout.split("output checksum")[1].split()[0])
+    ctx = filter_defaults(enable_low_pass_filter=0)
+    lin, lout = T.FrameLayout(3840, 1920), T.FrameLayout(1536, 1024)
+    with T.VideoFrameTransform(ctx) as t:
+        for idx, k in ((0, 0), (1, 1)):
+            assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+        d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        for j in range(F):
+            T.fill_noise(d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], T.frame_seed(j))
+        d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
+        _ready()
+        assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, F, t.plane_descs(lin, lout)) and t.synchronize()
+        want = int(d_out.to(torch.int64).sum().item())
+    assert got == want
