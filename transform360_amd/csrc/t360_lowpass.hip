@@ -325,6 +325,8 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
   for (int k = 0; k < KY; k++)
 #pragma unroll
     for (int p = 0; p < 4; p++) win[k][p] = 0u;
+  uint32_t half = 1u << 15;  // FixedPtCastEx's rounding term, in a register (v_mad_u32_u24 takes no literal)
+  asm volatile("" : "+v"(half));
 
   const uint32_t* __restrict__ lane_row = box + r0 * pitch + lir;
   uint8_t* __restrict__ d = dst + (size_t)(t.y0 + r0) * a.dstride + px0;
@@ -346,12 +348,15 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
           win[u][p] = acc;
         }
         if (r >= r0 + 2 * ry) {  // the window of output row r - 2 ry is complete: slots u+1 .. u (mod KY)
+          // KY multiply-adds per pixel, seeded with the rounding constant (hipcc, left alone, multiplies twice and adds
+          // three values: four instructions where three do)
           uint32_t c[4];
 #pragma unroll
           for (int p = 0; p < 4; p++) {
-            c[p] = 1u << 15;
+            c[p] = half;
 #pragma unroll
-            for (int k = 0; k < KY; k++) c[p] = __umul24(kyv[k], win[(u + 1 + k) % KY][p]) + c[p];
+            for (int k = 0; k < KY; k++)
+              asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(c[p]) : "v"(kyv[k]), "v"(win[(u + 1 + k) % KY][p]), "v"(c[p]));
           }
           // c >> 16 is 0 .. 256: saturate two at a time (v_sat_pk_u8_i16) instead of a v_min per pixel
           const uint32_t lo = sat_pk_u8_i16(__builtin_amdgcn_perm(c[1], c[0], 0x07060302u));  // [c0 >> 16, c1 >> 16] as i16
