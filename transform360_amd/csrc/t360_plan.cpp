@@ -358,43 +358,6 @@ class Planner {
      : s.kind == kTileWide128 ? st.n_wide128 : st.n_16)++;
   }
 
-  // Execution order = raster order of the tiles (row by row, left to right): horizontally adjacent tiles -- whose
-  // footprints end inside the same 128-byte lines of the source rows -- start back to back on the same XCD and
-  // walk the frames in step, so the shared lines come from HBM once and from that XCD's L2 the second time.
-  void raster_order(HostGatherPlan* out) const {
-    const size_t n = out->tiles.size();
-    std::vector<size_t> idx(n);
-    for (size_t i = 0; i < n; i++) idx[i] = i;
-    // order 2: Z-order over 64x16 cells (neighbours in BOTH directions are a few list positions apart)
-    auto morton = [](unsigned x, unsigned y) {
-      uint64_t m = 0;
-      for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
-      return m;
-    };
-    const bool z = opt_.order == 2;
-    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
-      const TileDesc& x = out->tiles[a];
-      const TileDesc& y = out->tiles[b];
-      if (z) {
-        const uint64_t mx = morton((unsigned)x.ox >> 6, (unsigned)x.oy >> 4), my = morton((unsigned)y.ox >> 6, (unsigned)y.oy >> 4);
-        if (mx != my) return mx < my;
-      }
-      return x.oy != y.oy ? x.oy < y.oy : x.ox < y.ox;
-    });
-    const size_t ws = (size_t)tile_words(opt_.ks, opt_.waves), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
-    std::vector<TileDesc> tiles(n);
-    std::vector<uint32_t> tlut(out->tlut.size()), chunks(out->chunks.size());
-    for (size_t i = 0; i < n; i++) {
-      tiles[i] = out->tiles[idx[i]];
-      std::copy(out->tlut.begin() + (long)(idx[i] * ws), out->tlut.begin() + (long)((idx[i] + 1) * ws), tlut.begin() + (long)(i * ws));
-      std::copy(out->chunks.begin() + (long)(idx[i] * cs), out->chunks.begin() + (long)((idx[i] + 1) * cs),
-                chunks.begin() + (long)(i * cs));
-    }
-    out->tiles.swap(tiles);
-    out->tlut.swap(tlut);
-    out->chunks.swap(chunks);
-  }
-
   // the tiles of one 128x32 output region, appended to `out` in execution order
   void plan_region(int rx, int ry, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
     const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
@@ -520,16 +483,15 @@ class Planner {
       for (auto& t : th) t.join();
     }
     if (failed.load()) return false;
-    out->tiles.clear();
-    out->tlut.clear();
-    out->chunks.clear();
+    // Assemble the plan: the execution order is decided on the descriptors alone, then every tile's tables are copied
+    // ONCE from the slice that planned it to their final place, on the same threads (a Lanczos4 plan of an 8K map is
+    // 330 MB of tables: appending the slices and re-ordering the result moved them three times on one thread).
     out->stats = PlanStats();
     std::vector<TileDesc> direct;
+    std::vector<std::pair<uint32_t, uint32_t>> where;  // concatenated tile -> (slice, tile inside the slice)
     for (size_t ti = 0; ti < nthreads; ti++) {
       const HostGatherPlan& p = part[ti];
-      out->tiles.insert(out->tiles.end(), p.tiles.begin(), p.tiles.end());
-      out->tlut.insert(out->tlut.end(), p.tlut.begin(), p.tlut.end());
-      out->chunks.insert(out->chunks.end(), p.chunks.begin(), p.chunks.end());
+      for (size_t k = 0; k < p.tiles.size(); k++) where.push_back({(uint32_t)ti, (uint32_t)k});
       direct.insert(direct.end(), part_direct[ti].begin(), part_direct[ti].end());
       PlanStats& a = out->stats;
       const PlanStats& b = p.stats;
@@ -540,7 +502,60 @@ class Planner {
       a.line_bytes += b.line_bytes;
       for (int i = 0; i < 33; i++) a.pieces_hist[i] += b.pieces_hist[i];
     }
-    if (opt_.order != 0) raster_order(out);
+    const size_t nt = where.size();
+    std::vector<size_t> idx(nt);
+    for (size_t i = 0; i < nt; i++) idx[i] = i;
+    if (opt_.order != 0) {
+      // order 1: raster; order 2: Z-order over 64x16 cells (neighbours in BOTH directions are a few list positions
+      // apart: horizontally and vertically adjacent tiles -- whose footprints share source lines -- start back to back
+      // on the same XCD and walk the frames in step, so the shared lines come from HBM once and from that XCD's L2
+      // the second time)
+      auto morton = [](unsigned x, unsigned y) {
+        uint64_t m = 0;
+        for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
+        return m;
+      };
+      const bool z = opt_.order == 2;
+      auto tile_at = [&](size_t i) -> const TileDesc& { return part[where[i].first].tiles[where[i].second]; };
+      std::vector<uint64_t> key(nt);
+      for (size_t i = 0; i < nt; i++) {
+        const TileDesc& t = tile_at(i);
+        key[i] = ((z ? morton((unsigned)t.ox >> 6, (unsigned)t.oy >> 4) : 0) << 32) | ((uint64_t)(uint16_t)t.oy << 16) | (uint16_t)t.ox;
+      }
+      std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+    }
+    const size_t ws = (size_t)tile_words(opt_.ks, opt_.waves), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+    out->tiles.assign(nt, TileDesc{});
+    out->tlut.assign(nt * ws, 0u);
+    out->chunks.assign(nt * cs, 0u);
+    auto copy_slice = [&](size_t ti) {
+      try {
+        for (size_t i = nt * ti / nthreads; i < nt * (ti + 1) / nthreads; i++) {
+          const HostGatherPlan& p = part[where[idx[i]].first];
+          const size_t k = where[idx[i]].second;
+          out->tiles[i] = p.tiles[k];
+          memcpy(&out->tlut[i * ws], &p.tlut[k * ws], ws * sizeof(uint32_t));
+          memcpy(&out->chunks[i * cs], &p.chunks[k * cs], cs * sizeof(uint32_t));
+        }
+      } catch (...) {
+        failed.store(true);
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      std::vector<size_t> here;
+      for (size_t ti = 1; ti < nthreads; ti++) {
+        try {
+          th.emplace_back(copy_slice, ti);
+        } catch (...) {
+          here.push_back(ti);
+        }
+      }
+      copy_slice(0);
+      for (size_t ti : here) copy_slice(ti);
+      for (auto& t : th) t.join();
+    }
+    if (failed.load()) return false;
     out->ntiles = (int)out->tiles.size();
     // direct tiles: upper half of the plane first (each pole's tiles go to one XCD, t360_remap_tiled.hip)
     std::stable_sort(direct.begin(), direct.end(), [&](const TileDesc& x, const TileDesc& y) {
