@@ -167,6 +167,36 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       tiles.push_back(std::move(t));
     }
   }
+  // T360_SIM_MERGE=x|y: model workgroups of twice the tile (256x16 / 128x32): the two tiles run in lock step
+  double per_frame_scale = 1.0;
+  if (const char* mg = getenv("T360_SIM_MERGE")) {
+    const bool mx = mg[0] == 'x';
+    std::vector<SimTile> merged;
+    std::vector<char> used(tiles.size(), 0);
+    for (size_t i = 0; i < tiles.size(); i++) {
+      if (used[i]) continue;
+      used[i] = 1;
+      SimTile t = tiles[i];
+      for (size_t j = 0; j < tiles.size(); j++) {
+        const SimTile& b = tiles[j];
+        if (used[j] || b.plane != t.plane || b.w != t.w || b.h != t.h) continue;
+        const bool adj = mx ? (b.oy == t.oy && (b.ox == t.ox + t.w || t.ox == b.ox + b.w) && (std::min(b.ox, t.ox) / t.w) % 2 == 0)
+                            : (b.ox == t.ox && (b.oy == t.oy + t.h || t.oy == b.oy + b.h) && (std::min(b.oy, t.oy) / t.h) % 2 == 0);
+        if (!adj) continue;
+        used[j] = 1;
+        t.chunks.insert(t.chunks.end(), b.chunks.begin(), b.chunks.end());
+        std::sort(t.chunks.begin(), t.chunks.end());
+        t.chunks.erase(std::unique(t.chunks.begin(), t.chunks.end()), t.chunks.end());
+        if (mx) t.ox = std::min(t.ox, b.ox), t.w *= 2; else t.oy = std::min(t.oy, b.oy), t.h *= 2;
+        break;
+      }
+      merged.push_back(std::move(t));
+    }
+    tiles.swap(merged);
+    staged_chunks = 0;
+    for (const SimTile& t : tiles) staged_chunks += (long long)t.chunks.size();
+    per_frame_scale = 0.5;  // twice the waves work on it
+  }
   const int total = (int)tiles.size();
   std::vector<std::vector<int>> neigh((size_t)total);
   for (int i = 0; i < total; i++)
@@ -272,7 +302,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
         }
       s.f++;
       s.done++;
-      const double pieces = (double)t.chunks.size() / 64.0;
+      const double pieces = per_frame_scale * (double)t.chunks.size() / 64.0;
       tnext[(size_t)si] += (ta + tb * pieces) * speed[(size_t)si] * (1.0 + 0.01 * jitter * uni(rng));
       tend = std::max(tend, tnext[(size_t)si]);
     }
