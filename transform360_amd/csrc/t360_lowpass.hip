@@ -363,7 +363,9 @@ __device__ __forceinline__ void lowpass_q8w_rows(const LowpassArgs& a, const Low
           const uint32_t hi = sat_pk_u8_i16(__builtin_amdgcn_perm(c[3], c[2], 0x07060302u));
           const uint32_t out = lo | (hi << 16);
           if (dword_out) {
-            *reinterpret_cast<uint32_t*>(d) = out;
+            // a streaming store: the filtered plane is read again only after ~700 MB of other traffic, and the lines it
+            // does not claim in the L2 are halo rows the tile below still finds there (-1 % on BASELINE config 3)
+            __builtin_nontemporal_store(out, reinterpret_cast<uint32_t*>(d));
           } else {
 #pragma unroll
             for (int p = 0; p < 4; p++)

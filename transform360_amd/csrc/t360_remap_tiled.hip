@@ -267,8 +267,16 @@ __device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // the value IS w
 #else
 #define T360_UNIFORM(p) (p)
 #endif
+// NT: a streaming store -- output lines are written once and never read, and every line they do not claim in the L2
+// is a source line a neighbouring workgroup may still find there (-1 % on the bicubic kernel; the nearest-neighbour
+// kernel, which shares nothing, measured 2 % slower with it; `nt` LOADS make the staging a third slower: they give up
+// exactly the lines the neighbours share.  tools/experiments_r03/gpu_call27.sh, gpu_call28.sh)
+template <bool NT>
 __device__ __forceinline__ void store_dword(uint8_t* base, uint32_t off, uint32_t v) {
-  asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+  if (NT)
+    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+  else
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ void store_byte(uint8_t* base, uint32_t off, uint32_t v) {
   asm volatile("global_store_byte %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
@@ -418,7 +426,7 @@ __device__ __forceinline__ void emit(const PixelSetup<NPX, KS>& s, uint32_t val,
   dbase = T360_UNIFORM(dbase);
   if (NPX == 4) {
     if (dword_store) {
-      store_dword(dbase, doff, val);
+      store_dword<KS != 1>(dbase, doff, val);
     } else {
 #pragma unroll
       for (int p = 0; p < NPX; p++)
