@@ -146,7 +146,8 @@ class VideoFrameTransform {
   int waves_ = 8;
   int frames_per_block_ = 64;  // frames one workgroup of the tiled gather walks with one tile (fewer, longer-lived workgroups:
                                // their start-up -- tables, weights, first DMA -- is ~5 us against ~1 us per frame)
-  int tail_percent_ = 12, tail_frames_ = 16;  // the last eighth of every XCD's tiles walks the batch in runs of 16 frames
+  int tail_percent_ = 12, tail_frames_ = 16;  // the last eighth of every XCD's tiles walks the batch in equal runs of <= 16
+                                               // frames, at least two (64 frames: 4 x 16; 20: 10 + 10; 8: 4 + 4)
                                                // (short workgroups drain the launch; each pays the ~5 us start-up again,
                                                // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
   int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
