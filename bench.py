@@ -690,7 +690,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=32)  # 32 x 64 = 2 048 frames inside one event bracket (>= 2 000)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64, help="frames per step per GPU (BASELINE config 5: 64)")
     ap.add_argument("--config", type=int, default=2)
