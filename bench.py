@@ -51,6 +51,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REPEATS = 5
+RING_BYTES = 320 << 20     # distinct input bytes the timed steps cycle through: more than the 256 MB Infinity Cache
 CLOCK_WARMUP_S = 0.4   # untimed load before the contract's warm-up steps (GPU clocks ramp)
 
 
@@ -260,10 +261,16 @@ class HipPath:
             assert self.t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
         assert self.t.setStream(self.stream)
         self.init_ms = (time.perf_counter() - t0) * 1e3
-        # synthetic stream: this rank's frames of one step, resident in HBM
-        self.d_in = torch.empty(F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
-        for j in range(F):
-            handler.fill_noise(self.d_in[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], self.seed_of(j))
+        # synthetic stream: this rank's frames of one step, resident in HBM.  When one step's input is smaller than the
+        # 256 MB Infinity Cache (short steps, small frames) the timed steps rotate through `groups` such batches --
+        # RING_BYTES of distinct input -- so that no step finds its source in a cache because the previous one read the
+        # same bytes.  Group 0 is the batch every other leg (verification, checksums, gathers) works on.
+        self.groups = max(1, -(-RING_BYTES // (F * lin.frame_bytes))) if F * lin.frame_bytes < RING_BYTES else 1
+        self.ring = torch.empty(self.groups * F * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        self.d_in = self.ring[:F * lin.frame_bytes]
+        for j in range(self.groups * F):
+            seed = self.seed_of(j) if j < F else handler.frame_seed(1_000_000 + rank * 100_000 + j)
+            handler.fill_noise(self.ring[j * lin.frame_bytes:(j + 1) * lin.frame_bytes], seed)
         self.d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8, device="cuda")
         self.descs = self.t.plane_descs(lin, lout)
 
@@ -450,8 +457,13 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             dist.barrier()
             path.sync()
 
-    def timed_run(n_frames, steps, with_events, after_step=None):
-        """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms])."""
+    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False):
+        """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms]).
+        rotate: step k reads the k-th group of n_frames input frames of this rank's F (a short step must not find its
+        input in the 256 MB Infinity Cache just because every step reads the same few frames)."""
+        ring_frames = getattr(path, "groups", 1) * F
+        groups = max(1, ring_frames // n_frames) if rotate else 1
+        ring = getattr(path, "ring", None) if groups > 1 else None
         out = []
         for _ in range(REPEATS):
             # ONE event pair around the K launches of the timed region (on the stream the kernels run on): the average
@@ -463,7 +475,10 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             if events is not None:
                 path.mark(events, 0)
             for k in range(steps):
-                path.step(n_frames)
+                if ring is not None:
+                    path.step(n_frames, inp=ring[(k % groups) * n_frames * lin.frame_bytes:])
+                else:
+                    path.step(n_frames)
                 if after_step is not None:
                     after_step(k)
             if events is not None:
@@ -497,7 +512,11 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         clock_warmup_steps += 8
     for _ in range(args.warmup):
         path.step(F)
-    runs = timed_run(F, args.steps, True)
+    rotate = not os.environ.get("T360_BENCH_NO_ROTATE")
+    runs = timed_run(F, args.steps, True, rotate=rotate)
+    if getattr(path, "groups", 1) > 1:
+        path.step(F)  # d_out holds group 0's result again
+        path.sync()
     elapsed, launch_ms = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     kernel_name = path.kernel_name()
 
@@ -508,7 +527,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     if args.config == 2:
         for _ in range(max(2, args.warmup)):
             path.step(f5)
-        sruns = timed_run(f5, args.steps, False)
+        sruns = timed_run(f5, args.steps, False, rotate=rotate)
         s_el = sorted(r[0] for r in sruns)[len(sruns) // 2]
         strong = {"frames_total": 64, "frames_per_gpu": f5, "n_gpus": world, "scaling": "strong",
                   "ms_per_step": round(s_el / args.steps * 1e3, 4),
@@ -661,6 +680,8 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             "fps": round(fps, 1),
             "repeats": REPEATS, "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in runs],
             "clock_warmup_steps": clock_warmup_steps,
+            "input_ring": {"groups_of_F_frames": getattr(path, "groups", 1), "bytes": getattr(path, "groups", 1) * F * lin.frame_bytes,
+                           "why": "timed steps rotate through this much distinct input when one step's input would fit the 256 MB Infinity Cache"},
             "frames_timed_per_gpu": REPEATS * args.steps * F,
             "frac_of_hbm_roofline_whole_job": round(alg_frame * fps / (HBM_PEAK_BPS * world), 4),
             "roofline": {
