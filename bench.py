@@ -533,6 +533,12 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                   "ms_per_step": round(s_el / args.steps * 1e3, 4),
                   "value": round(min(64, f5 * world) * args.steps / s_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
                   "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in sruns]}
+        if rotate and getattr(path, "groups", 1) * F > f5:
+            # the same f5 input frames every step (88 MB for 8 frames: they stay in the 256 MB Infinity Cache)
+            cruns = timed_run(f5, args.steps, False, rotate=False)
+            c_el = sorted(r[0] for r in cruns)[len(cruns) // 2]
+            strong["input"] = "every step reads other frames of the rank's %d-frame ring (HBM)" % (getattr(path, "groups", 1) * F)
+            strong["ms_per_step_same_input_every_step"] = round(c_el / args.steps * 1e3, 4)
         if f5 * world != 64:
             strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
 
