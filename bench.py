@@ -756,6 +756,11 @@ def main():
             raise SystemExit("--gpus %d but only %d GPU(s) visible (T360_DIST_BACKEND=gloo rehearses the multi-rank "
                              "path on fewer devices)" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+        if backend != "nccl" and world > 1 and (args.gather_outputs or args.scatter_inputs):
+            # gloo has no gather / scatter for tensors in device memory (the calls never complete: a 10-minute hang on
+            # the GPU box, 2026-09-24); these legs move frames between GPUs and need RCCL -- their gloo rehearsal is --stub
+            raise SystemExit("--gather-outputs / --scatter-inputs with frames in HBM need the nccl (RCCL) backend; "
+                             "rehearse these legs on CPU with --stub")
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
