@@ -33,9 +33,10 @@
 //     that every XCD gets a contiguous range of the execution-ordered (Z-order) tile list: shared halo -> shared L2.
 //   * no MFMA: this is a gather, not a contraction.
 //   * what bounds it (measured): staging alone 0.245 ms, gathering alone 0.205 ms, both 0.25 ms per 64
-//     frames of BASELINE config 2 -- memory throughput (1.34 GB per launch at 5.5 TB/s, 1.56x the algorithmic bytes:
-//     neighbouring tiles drift apart in frame number and re-fetch the lines they share) and instruction issue (~90
-//     VALU per 4 pixels and frame, 60 % of a SIMD's cycles) are within 20 % of each other.
+//     frames of BASELINE config 2 -- memory throughput (1.31 GB per launch at 5.4 TB/s, 1.53x the algorithmic bytes:
+//     neighbouring tiles drift apart in frame number and re-fetch the lines they share) and the per-frame dependency chain
+//     of a wave (LDS reads -> dot products -> barrier; ~94 VALU per wave and frame, VALUs 36 % and LDS 41 % busy) are
+//     within 20 % of each other.
 #include <hip/hip_runtime.h>
 
 #include "t360_internal.h"
