@@ -323,19 +323,25 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
             d[r][k] = *reinterpret_cast<const uint32_t*>(lds + s.addr[0][4 * h + r] + SLOT + 4 * k);
           }
         }
-      if (T360_ASMREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count asm loads
+      // hipcc does not count asm loads.  LDS returns in order: a row's three dwords are there when at most the reads of
+      // the rows behind it are outstanding, and its eight products run while those are still on their way
 #pragma unroll
-      for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++) {
+        if (T360_ASMREAD) {
+          if (r == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+          if (r == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          if (r == 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+          if (r == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) asm volatile("" : "+v"(d[r][k]));
-#pragma unroll
-      for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int w = 0; w < 2; w++) {
           const uint32_t px4 = __builtin_amdgcn_alignbit(d[r][w + 1], d[r][w], sh);
           hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[0][(4 * h + r) * 2 + w], hi, false);
           lo = __builtin_amdgcn_udot4(px4, s.wl[0][(4 * h + r) * 2 + w], lo, false);
         }
+      }
     }
     v[0] = sat_u8(((hi << 8) + (int)lo) >> kCoefBits);
   } else {
