@@ -302,44 +302,39 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
 #pragma unroll
     for (int p = 0; p < NPX; p++) v[p] = lds[s.addr[p][0] + SLOT];
   } else if (KS == 8) {
-    // Lanczos4: 8 rows x 8 taps.  The rows go through in two halves (12 LDS dwords in flight each) and every window
-    // is consumed as soon as it is assembled: the 64 weights already take 32 registers per pixel.
+    // Lanczos4: 8 rows x 8 taps, every window consumed as soon as it is assembled: the 64 weights already take 32
+    // registers per pixel.  (Two halves of 12 dwords with one wait each: 3.63 ms per 64 frames of BASELINE config 4;
+    // counted waits per row: 3.54; all 24 dwords up front: 3.50.)
     static_assert(KS != 8 || NPX == 1, "Lanczos4 tiles hold one pixel per lane");
     const uint32_t sh = s.sh[0];
     int hi = s.hb[0];
     uint32_t lo = 1u << (kCoefBits - 1);
+    {
+      // all 24 dwords of the stencil up front, rows consumed as they arrive (the LGKM counter has 4 bits: rows 0-2 wait for
+      // "at most 15 outstanding", which 24 - 9 = 15 reads behind row 2 make exact for row 2 and generous for rows 0, 1)
+      uint32_t d[8][3];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t d[4][3];
-#pragma unroll
-      for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 8; r++)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          if (T360_ASMREAD) {
-            // the ring slot as the immediate offset of ds_read_b32 (see the bicubic branch below)
-            const uint32_t la = (uint32_t)(uintptr_t)lds + s.addr[0][4 * h + r];
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d[r][k]) : "v"(la), "n"(SLOT + 4 * k));
-          } else {
-            d[r][k] = *reinterpret_cast<const uint32_t*>(lds + s.addr[0][4 * h + r] + SLOT + 4 * k);
-          }
+          const uint32_t la = (uint32_t)(uintptr_t)lds + s.addr[0][r];
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d[r][k]) : "v"(la), "n"(SLOT + 4 * k));
         }
-      // hipcc does not count asm loads.  LDS returns in order: a row's three dwords are there when at most the reads of
-      // the rows behind it are outstanding, and its eight products run while those are still on their way
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if (T360_ASMREAD) {
-          if (r == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
-          if (r == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-          if (r == 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-          if (r == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+      for (int r = 0; r < 8; r++) {
+        if (r == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        if (r == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        if (r == 4) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+        if (r == 5) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        if (r == 6) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        if (r == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 3; k++) asm volatile("" : "+v"(d[r][k]));
 #pragma unroll
         for (int w = 0; w < 2; w++) {
           const uint32_t px4 = __builtin_amdgcn_alignbit(d[r][w + 1], d[r][w], sh);
-          hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[0][(4 * h + r) * 2 + w], hi, false);
-          lo = __builtin_amdgcn_udot4(px4, s.wl[0][(4 * h + r) * 2 + w], lo, false);
+          hi = __builtin_amdgcn_sdot4((int)bias128(px4), (int)s.wh[0][r * 2 + w], hi, false);
+          lo = __builtin_amdgcn_udot4(px4, s.wl[0][r * 2 + w], lo, false);
         }
       }
     }
