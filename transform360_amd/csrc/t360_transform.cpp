@@ -176,6 +176,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
     return;
   }
   stream_ = own_stream_;
+  if (hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, device_) != hipSuccess || cus_ <= 0) cus_ = 256;
   for (int k = 0; k < 3; k++)
     if (hipStreamCreateWithFlags(&lp_streams_[k], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&lp_join_[k], hipEventDisableTiming) != hipSuccess) {
@@ -1055,6 +1056,18 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   };
   auto flush_fused = [&]() -> bool {
     if (fused.nplanes == 0) return true;
+    // A launch with fewer work items than 1.5 x the workgroups the GPU holds at once ends on a nearly empty machine
+    // (BASELINE config 1: 576 tiles for 512 slots = one full round and one of 64 workgroups, 64 frames each): every
+    // tile's frames are split into more runs until the items pass that mark (config 1, 64 frames: 0.082 -> 0.064 ms with
+    // two runs of 32; 16 frames on the 4-wave plan: 0.023 -> 0.020 ms).  Runs stay >= 8 frames, a workgroup's start-up
+    // being worth ~5 of them; BASELINE config 2 (1 152 tiles) is not affected.
+    {
+      const int slots = cus_ * (fused.waves == 8 ? 2 : 4);
+      const int tiles = fused.total_tiles + fused.total_direct;
+      int runs = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+      while (tiles > 0 && 2 * tiles * runs < 3 * slots && n_frames / (runs + 1) >= 8) runs++;
+      fused.frames_per_block = std::min(fused.frames_per_block, (n_frames + runs - 1) / runs);
+    }
     fused.groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
     // the tail tiles walk the batch in at least two runs of <= tail_frames_ frames, all of EQUAL length (20 frames:
     // 10 + 10, not 16 + 4: -6 %; 8 frames: 4 + 4: -2 %)

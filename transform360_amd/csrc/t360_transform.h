@@ -150,6 +150,7 @@ class VideoFrameTransform {
                                                // frames, at least two (64 frames: 4 x 16; 20: 10 + 10; 8: 4 + 4)
                                                // (short workgroups drain the launch; each pays the ~5 us start-up again,
                                                // so more than ~15 % costs more than it saves: measured 5 .. 35 %)
+  int cus_ = 256;              // compute units of the device (how many workgroups a launch needs to fill it)
   int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
   static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
