@@ -342,7 +342,11 @@ class StubPath:
         self.lin, self.lout, self.F, self.rank = lin, lout, F, rank
         self.init_ms = 0.0
         from transform360_amd.handler import frame_seed, noise_bytes
-        self.d_in = torch.from_numpy(np_concat([noise_bytes(lin.frame_bytes, frame_seed(rank * F + j)) for j in range(F)]))
+        # two groups of F frames, like a HipPath whose step would fit the Infinity Cache: the timed steps rotate
+        self.groups = 2
+        self.ring = torch.from_numpy(np_concat([noise_bytes(lin.frame_bytes, frame_seed(rank * F + j if j < F else 1_000_000 + rank * 100_000 + j))
+                                                for j in range(self.groups * F)]))
+        self.d_in = self.ring[:F * lin.frame_bytes]
         self.d_out = torch.zeros(F * lout.frame_bytes, dtype=torch.uint8)
 
     def step(self, n_frames, events=None, out=None, inp=None):

@@ -266,6 +266,8 @@ def test_bench_rank_function_world_size_2_gloo():
     assert len(rec["output_checksums"]) == 2 and rec["output_checksums"][0] != rec["output_checksums"][1]
     s = rec["strong_cfg5"]
     assert s["n_gpus"] == 2 and s["frames_per_gpu"] == 6 and "note" in s   # 64 / 2 = 32 > --frames 6: said so
+    assert rec["input_ring"]["groups_of_F_frames"] == 2   # the timed steps rotated through two input batches ...
+    assert rec["verified"]["frames"]                        # ... and the verified result is group 0's again
     g = rec["gather_outputs"]
     assert g["bytes_to_rank0_per_step"] > 0 and g["ms_per_step"] > 0 and "gloo" in g["collective"]
     x = rec["scatter_gather"]
