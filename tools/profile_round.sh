@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile_round.sh <tag> : the profile set committed under profiles/ for one round.
-#   1. the plain bench.py line of this build (with --gather-outputs)               -> profiles/<tag>_bench_default.json
+#   1. the plain bench.py line of this build (with --gather-outputs; run last)     -> profiles/<tag>_bench_default.json
 #      and the 8-frame batch (BASELINE configs[4] per GPU of an 8-GPU node)        -> profiles/<tag>_bench_8frames.json
 #   2. rocprofv3 --kernel-trace --stats of the default run (config 2)              -> profiles/<tag>_kernel_stats.csv
 #      of configs 1, 3, 4                                                          -> profiles/<tag>_cfgN_kernel_stats.csv
@@ -15,8 +15,6 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$R/profiles"
 cd /tmp && export TMPDIR=/tmp
-python "$R/bench.py" --gather-outputs > "$OUT/bench_default.log" 2>&1
-grep -h "^{\"metric\"" "$OUT/bench_default.log" | tail -1 > "$R/profiles/${TAG}_bench_default.json"
 python "$R/bench.py" --frames 8 --no-cpu-baseline --no-host-abi > "$OUT/bench_8frames.log" 2>&1
 grep -h "^{\"metric\"" "$OUT/bench_8frames.log" | tail -1 > "$R/profiles/${TAG}_bench_8frames.json"
 for CFG in 2 1 3 4; do
@@ -37,6 +35,9 @@ for CFG in 1 3 4; do
   cp "$OUT/pmc_cfg$CFG/summary.txt" "$R/profiles/${TAG}_cfg${CFG}_pmc_summary.txt"
   python tools/make_traffic.py "$OUT/pmc_cfg$CFG" $CFG 64 "$R/profiles/${TAG}_cfg${CFG}_traffic.json"
 done
+# the default line LAST: it then finds the traffic record of this very build (bench.py compares the library's sha256)
+python "$R/bench.py" --gather-outputs > "$OUT/bench_default.log" 2>&1
+grep -h "^{\"metric\"" "$OUT/bench_default.log" | tail -1 > "$R/profiles/${TAG}_bench_default.json"
 mkdir -p "$R/gpurun_out/profiles" && cp "$R/profiles/${TAG}"* "$R/gpurun_out/profiles/"
 head -4 "$R/profiles/${TAG}_kernel_stats.csv" | cut -c1-200
 cat "$R/profiles/${TAG}_traffic.json" "$R/profiles/${TAG}_cfg3_traffic.json"
