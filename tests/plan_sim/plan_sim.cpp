@@ -29,6 +29,16 @@ extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, 
   for (int i = 0; i < plan.ntiles; i++) maxp = plan.tiles[i].pieces > maxp ? plan.tiles[i].pieces : maxp;
   stats[11] = maxp;
   for (int i = 0; i < 33; i++) stats[12 + i] = s.pieces_hist[i];
+  // FNV-1a over the plan's three tables: two builds of the planner that agree here emit the same plan
+  auto fnv = [](const void* p, size_t n) {
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    return (long long)h;
+  };
+  stats[50] = fnv(plan.tiles.data(), plan.tiles.size() * sizeof(plan.tiles[0]));
+  stats[51] = fnv(plan.tlut.data(), plan.tlut.size() * 4);
+  stats[52] = fnv(plan.chunks.data(), plan.chunks.size() * 4);
   return 1;
 }
 
