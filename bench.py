@@ -461,7 +461,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             dist.barrier()
             path.sync()
 
-    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False):
+    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False, before_step=None):
         """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms]).
         rotate: step k reads the k-th group of n_frames input frames of this rank's F (a short step must not find its
         input in the 256 MB Infinity Cache just because every step reads the same few frames)."""
@@ -479,6 +479,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             if events is not None:
                 path.mark(events, 0)
             for k in range(steps):
+                path.k = k  # the double-buffered legs pick their buffers from the step number of THIS timed region
+                if before_step is not None:
+                    before_step(k)
                 if ring is not None:
                     path.step(n_frames, inp=ring[(k % groups) * n_frames * lin.frame_bytes:])
                 else:
@@ -503,6 +506,21 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     # back: the first repeats used to read 5-15 % slow.  Untimed steps for CLOCK_WARMUP_S seconds first (they also build
     # the gather plan, which the library makes on the first call that needs it), then the W warm-up steps of the
     # contract, then the timed repeats.
+    rotate = not os.environ.get("T360_BENCH_NO_ROTATE")
+
+    def warm_steps(n_frames, count, start=0):
+        """untimed steps that read the input the way the timed ones will (rotating through the ring when one step's input
+        would fit the Infinity Cache): a kernel trace of the whole process then averages HBM-resident launches only"""
+        ring_frames = getattr(path, "groups", 1) * F
+        groups = max(1, ring_frames // n_frames) if rotate else 1
+        ring = getattr(path, "ring", None) if groups > 1 else None
+        for k in range(start, start + count):
+            path.k = k
+            if ring is not None:
+                path.step(n_frames, inp=ring[(k % groups) * n_frames * lin.frame_bytes:])
+            else:
+                path.step(n_frames)
+
     clock_warmup_steps = 0
     t_first = time.perf_counter()
     path.step(F)
@@ -510,13 +528,10 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     first_step_ms = (time.perf_counter() - t_first) * 1e3
     t_w = time.perf_counter()
     while path.name == "hip" and time.perf_counter() - t_w < CLOCK_WARMUP_S:
-        for _ in range(8):
-            path.step(F)
+        warm_steps(F, 8, clock_warmup_steps)
         path.sync()
         clock_warmup_steps += 8
-    for _ in range(args.warmup):
-        path.step(F)
-    rotate = not os.environ.get("T360_BENCH_NO_ROTATE")
+    warm_steps(F, args.warmup)
     runs = timed_run(F, args.steps, True, rotate=rotate)
     if getattr(path, "groups", 1) > 1:
         path.step(F)  # d_out holds group 0's result again
@@ -529,8 +544,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     strong = None
     f5 = min(F, -(-64 // world))
     if args.config == 2:
-        for _ in range(max(2, args.warmup)):
-            path.step(f5)
+        warm_steps(f5, max(2, args.warmup))
         sruns = timed_run(f5, args.steps, False, rotate=rotate)
         s_el = sorted(r[0] for r in sruns)[len(sruns) // 2]
         strong = {"frames_total": 64, "frames_per_gpu": f5, "n_gpus": world, "scaling": "strong",
@@ -574,13 +588,18 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
 
         step_plain = path.step
 
-        def step_alt(n_frames, events=None, out=None, _k=[0]):
-            step_plain(n_frames, events, bufs[_k[0] & 1])
-            _k[0] += 1
+        def step_alt(n_frames, events=None, out=None):
+            # step k writes bufs[k & 1], the buffer gather_step(k) sends: k is the step number inside the timed region
+            # (a private counter that kept running through the warm-up steps sent the stale buffer)
+            step_plain(n_frames, events, bufs[path.k & 1])
 
         path.step = step_alt
-        for _ in range(max(2, args.warmup)):
+        for w in range(2 * max(1, args.warmup // 2)):  # an even number: the timed region starts on buffer 0
+            path.k = w
             path.step(F)
+            gather_step(w)
+        gather_step(None)
+        pending[0] = pending[1] = None
         gruns = timed_run(F, args.steps, False, after_step=gather_step)
         path.step = step_plain
         g_el = sorted(r[0] for r in gruns)[len(gruns) // 2]
@@ -607,34 +626,46 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         sink = [torch.empty_like(outs[0]) for _ in range(world)] if rank == 0 else None
         pend_in, pend_out = [None, None], [None, None]
 
+        def feed_step(k):
+            """before step k is launched: the buffers it uses are free, and the NEXT step's input starts moving.  The
+            scatter is issued before step k, so the collective's stream waits only for step k-1 (the last reader of
+            that buffer) and runs beside step k; issued after step k it would queue behind it."""
+            b, nb = k & 1, (k + 1) & 1
+            for q in (pend_out, pend_in):      # step k reads ins[b] and writes outs[b]
+                if q[b] is not None:
+                    q[b].wait()
+                    q[b] = None
+            if dist is not None:
+                pend_in[nb] = dist.scatter(ins[nb], src_all if rank == 0 else None, src=0, async_op=True)
+            else:
+                ins[nb].copy_(src_all[0], non_blocking=True)
+
         def move_step(k):
             if k is None:
                 for w in pend_in + pend_out:
                     if w is not None:
                         w.wait()
+                pend_in[0] = pend_in[1] = pend_out[0] = pend_out[1] = None
                 return
-            b, nb = k & 1, (k + 1) & 1
+            b = k & 1
             if dist is not None:
                 pend_out[b] = dist.gather(outs[b], sink if rank == 0 else None, dst=0, async_op=True)
-                pend_in[nb] = dist.scatter(ins[nb], src_all if rank == 0 else None, src=0, async_op=True)
             else:
                 sink[0].copy_(outs[b], non_blocking=True)
-                ins[nb].copy_(src_all[0], non_blocking=True)
-            for q in (pend_out, pend_in):      # the next step reads ins[nb] and writes outs[nb]
-                if q[nb] is not None:
-                    q[nb].wait()
-                    q[nb] = None
 
         step_plain = path.step
 
-        def step_alt(n_frames, events=None, out=None, inp=None, _k=[0]):
-            step_plain(n_frames, events, outs[_k[0] & 1], ins[_k[0] & 1])
-            _k[0] += 1
+        def step_alt(n_frames, events=None, out=None, inp=None):
+            step_plain(n_frames, events, outs[path.k & 1], ins[path.k & 1])
 
         path.step = step_alt
-        for _ in range(max(2, args.warmup)):
+        for w in range(2 * max(1, args.warmup // 2)):
+            path.k = w
+            feed_step(w)
             path.step(F)
-        xruns = timed_run(F, args.steps, False, after_step=move_step)
+            move_step(w)
+        move_step(None)
+        xruns = timed_run(F, args.steps, False, after_step=move_step, before_step=feed_step)
         path.step = step_plain
         x_el = sorted(r[0] for r in xruns)[len(xruns) // 2]
         scattered = {"what": "each step's %d input frames per rank scattered from rank 0 into the next step's buffer and its "

@@ -151,12 +151,18 @@ int main(int argc, char** argv) {
         CHECK_HIP(hipEventRecord(sent[b], side));
       }
     };
-    // warm-up: the first step plans the gather, and the clocks need a few hundred milliseconds of load to come up
+    // warm-up in two parts.  (1) The clock ramp -- the first step plans the gather, and the clocks need a few hundred
+    // milliseconds of load to come up -- runs the transform ALONE: its length is this thread's own wall clock, and a
+    // loop of that kind must not post collectives (devices would post different numbers of sends and receives and
+    // the side streams would never drain).  (2) A FIXED number of full steps, the same on every device, primes the
+    // gather path and its double buffering.
     for (const auto w0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - w0 < std::chrono::milliseconds(400);) {
-      for (int k = 0; k < 8; k++) step(k);
+      for (int k = 0; k < 8; k++)
+        if (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[k & 1], lout.frame_bytes, F, planes, 3)) exit(1);
       CHECK_HIP(hipStreamSynchronize(stream));
-      CHECK_HIP(hipStreamSynchronize(side));
     }
+    constexpr int kWarmSteps = 4;  // even: the timed loop starts on buffer 0 with both `sent` events recorded
+    for (int k = 0; k < kWarmSteps; k++) step(k);
     CHECK_HIP(hipStreamSynchronize(stream));
     CHECK_HIP(hipStreamSynchronize(side));
     const auto t0 = std::chrono::steady_clock::now();

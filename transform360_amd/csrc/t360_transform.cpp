@@ -1178,8 +1178,8 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   return flush_fused();
 }
 
-// Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host once (here, when the map is
-// generated) and planned there (t360_plan.cpp) -- LAZILY, by the first call that needs the plan: batches of fewer than
+// Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host and planned there
+// (t360_plan.cpp) -- LAZILY, by the first call that needs the plan (ensureGatherPlan): batches of fewer than
 // small_batch_ frames (and the single-plane calls of the reference ABI) use the plan for workgroups of 4 waves, longer
 // batches the one for 8 waves, and a caller normally lives in one of the two regimes, so planning both at init would
 // double the first-frame latency for nothing (the filter initialises inside its first filter_frame, vf_transform360.c:
@@ -1189,28 +1189,32 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
   p.plan.valid = p.plan.tried = false;
   p.plan_small.valid = p.plan_small.tried = false;
   p.plan_ks = 0;
-  p.host_lut.clear();
   const bool barrel = P.output_layout == LAYOUT_BARREL || P.output_layout == LAYOUT_BARREL_SPLIT;
   const int ks = P.interp == NEAREST ? 1 : P.interp == LINEAR ? 2 : P.interp == CUBIC ? 4 : P.interp == LANCZOS4 ? 8 : 0;
   if (ks == 0 || barrel || !use_tiled_ || (in_w & 15) != 0) return true;
-  const size_t n = (size_t)P.map_w * (size_t)P.map_h;
-  try {
-    p.host_lut.resize(n);
-  } catch (const std::exception&) {
-    p.host_lut.clear();
-    return true;  // no host memory for the planner's copy: the general gather serves the map
-  }
-  if (!check(hipMemcpyAsync(p.host_lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
-      !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
-    return false;
   p.plan_ks = ks;
   return true;
 }
 
 bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   PlaneState::GatherPlan& g = small ? p.plan_small : p.plan;
-  if (g.valid || g.tried || p.plan_ks == 0 || p.host_lut.empty()) return true;
+  if (g.valid || g.tried || p.plan_ks == 0) return true;
   g.tried = true;  // not plannable stays not plannable: the general gather serves the map
+  // The planner works on a host copy of the sample LUT.  It is fetched from device memory HERE and lives for this
+  // call only (12.6 MB for the 4K luma map, up to 2^28 entries x 8 B for the largest map the ABI admits): a handle
+  // never holds a host copy between calls, whichever regimes it ends up planning.
+  std::vector<LutEntry> host_lut;
+  {
+    const size_t n = (size_t)p.map_w * (size_t)p.map_h;
+    try {
+      host_lut.resize(n);
+    } catch (const std::exception&) {
+      return true;  // no host memory for the planner's copy: the general gather serves the map
+    }
+    if (!check(hipMemcpyAsync(host_lut.data(), p.lut.as<void>(), n * sizeof(LutEntry), hipMemcpyDeviceToHost, stream_), "hipMemcpy(lut)") ||
+        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+      return false;
+  }
   const int ks = p.plan_ks;
   const int waves = small || ks == 8 ? 4 : waves_;
   const int max_pieces = ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
@@ -1225,7 +1229,7 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   o.row_pad = plan_row_pad_;
   o.row_align = plan_row_align_;
   HostGatherPlan hp;
-  if (!plan_gather(p.host_lut.data(), p.map_w, p.map_h, p.in_w, p.in_h, o, &hp)) return true;
+  if (!plan_gather(host_lut.data(), p.map_w, p.map_h, p.in_w, p.in_h, o, &hp)) return true;
   if (!g.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
       !g.tlut.reserve(hp.tlut.size() * sizeof(uint32_t)) || !g.chunks.reserve(hp.chunks.size() * sizeof(uint32_t)))
     return check(hipErrorOutOfMemory, "hipMalloc(gather plan)");
@@ -1245,9 +1249,6 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   g.waves = waves;
   g.max_pieces = max_pieces;
   g.valid = true;
-  // both regimes planned (or only one exists): the host copy of the LUT has served its purpose
-  const bool other_done = ks == 8 || waves_ == 4 || small_batch_ <= 0 || (small ? p.plan.tried : p.plan_small.tried);
-  if (other_done) std::vector<LutEntry>().swap(p.host_lut);
   return true;
 }
 

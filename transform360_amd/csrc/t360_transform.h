@@ -98,7 +98,6 @@ class VideoFrameTransform {
       t360::DeviceBuffer tiles, tlut, chunks;
       t360::PlanStats stats;
     } plan, plan_small;  // plan_small: workgroups of 4 waves, for batches shorter than small_batch_ frames
-    std::vector<t360::LutEntry> host_lut;  // host copy of the LUT until the plans are built (lazily, ensureGatherPlan)
     int plan_ks = 0;                       // taps per axis the plans are for; 0: the tiled kernel cannot take this map
   };
 
