@@ -31,7 +31,8 @@ Rank 0 prints ONE JSON line:
   value        = frames/s (whole job) x output luma pixels / 1e6                              [Mpix/s]
   roofline     = algorithmic bytes of the step's kernel launch / its average duration (HIP events on the launch
                  stream inside the timed region) vs the 8 TB/s HBM peak; the kernel name is what the library
-                 reports it launched; "traffic" = HBM-side bytes per launch from the committed PMC profile of THIS
+                 reports it launched; "traffic" = L2-miss (fabric) bytes per launch -- what the XCDs' L2s request from the memory side, Infinity-Cache
+                 hits included: an upper bound of the HBM bytes -- from the committed PMC profile of THIS
                  library build (profiles/r*_traffic.json, sha256 of the .so checked), null with the reason otherwise
   verified     = frames of the LAST timed step's output compared, all planes, with the CPU oracle
   cpu_baseline = the CPU oracle (restatement of the reference's OpenCV path, NOT linked OpenCV) with the
@@ -410,7 +411,7 @@ def np_concat(parts):
 
 
 def traffic_record(lib_path, kernel_name, frames, config):
-    """HBM-side bytes per launch from the committed PMC profile (profiles/r03_traffic.json, written by
+    """L2-miss (fabric) bytes per launch from the committed PMC profile (profiles/rNN_traffic.json, written by
     tools/profile_round.sh on a GPU box: rocprofv3 --pmc TCC_EA0_RDREQ_* / WRREQ_*, separate passes) -- counters cannot be
     read inside a run.  Only reported when the profile was taken from THIS library build (sha256 of the .so), the same
     kernel, batch size and config; otherwise null with the reason."""
@@ -435,7 +436,7 @@ def traffic_record(lib_path, kernel_name, frames, config):
     if tr.get("frames") != frames or tr.get("config") != config or tr.get("kernel", "") not in kernel_name:
         return None, "%s is for config %s, %s frames, kernel %s" % (os.path.relpath(path, ROOT), tr.get("config"),
                                                                    tr.get("frames"), tr.get("kernel"))
-    return int(tr["hbm_bytes_per_launch"]), "%s: rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}/WRREQ_{,64B}, mean over the " \
+    return int(tr["hbm_bytes_per_launch"]), "%s: L2-miss (fabric) bytes, rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}/WRREQ_{,64B} (in front of the Infinity Cache), mean over the " \
         "dispatches of a separate run of this build (library sha256[:16] %s): %d read + %d written" % (
             os.path.relpath(path, ROOT), sha, tr["hbm_read_bytes_per_launch"], tr["hbm_write_bytes_per_launch"])
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (tools/prof_pmc.sh
+"""L2-miss (fabric) bytes per launch of the dominant kernel from rocprofv3 PMC passes (tools/prof_pmc.sh
 with PMC_MEM=1), for bench.py's roofline.traffic field.
 
 Uses the L2's memory-side request counters by size, which need no unit correction:
@@ -39,24 +39,31 @@ res = {"config": config, "frames": frames, "grid": name[1],
        "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
        "hbm_bytes_per_launch": int(rd + wr),
        "fetch_size_kib_x2_bytes": int(m.get("FETCH_SIZE", 0) * 1024 * 2),
-       "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum, mean over dispatches"}
-# all kernels of a step (config 3: the low-pass launches too): bytes summed over every dispatch / steps
-steps = len(acc[name].get("TCC_EA0_RDREQ_sum", [])) or 1
+       "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ_{,64B}_sum, mean over dispatches",
+       "what": "L2-miss (fabric) bytes: requests the XCDs' L2s send to the memory side.  Infinity-Cache hits are INCLUDED "
+               "(the counters sit in front of the MALL), so this is an upper bound of the HBM bytes"}
+# all kernels of a step (config 3: the low-pass launches too).  Every counter comes from its own pass, and the passes do not
+# see the same number of dispatches (r03: RDREQ 1 199 samples, WRREQ 975): each counter is averaged over ITS OWN samples,
+# and a kernel's launches per step come from one reference pass (the RDREQ one) -- dividing every sum by the RDREQ sample
+# count understated the writes by 19-25 % (VERDICT round 3, weak point 8).
+ref = "TCC_EA0_RDREQ_sum"
+steps = len(acc[name].get(ref, [])) or 1
 tot_rd = tot_wr = 0.0
 per_kernel = {}
 for k, c in acc.items():
     if "fill_noise" in k[0] or "mapgen" in k[0]:
         continue
-    g = lambda n: sum(c.get(n, []))  # noqa: E731
+    per_step = len(c.get(ref, [])) / steps          # launches of this kernel per step
+    g = lambda n: (sum(c[n]) / len(c[n]) if c.get(n) else 0.0) * per_step  # noqa: E731  mean per launch x launches per step
     krd = 32 * g("TCC_EA0_RDREQ_32B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 128 * g("TCC_EA0_RDREQ_128B_sum")
     kwr = 64 * g("TCC_EA0_WRREQ_64B_sum") + 32 * (g("TCC_EA0_WRREQ_sum") - g("TCC_EA0_WRREQ_64B_sum"))
     short = re.search(r"(\w+_kernel)", k[0])
     key = "%s grid %s" % (short.group(1) if short else k[0][:40], k[1])
-    per_kernel[key] = {"read_bytes_per_step": int(krd / steps), "write_bytes_per_step": int(kwr / steps),
-                       "dispatches_per_step": round(len(c.get("TCC_EA0_RDREQ_sum", [])) / steps, 2)}
+    per_kernel[key] = {"read_bytes_per_step": int(krd), "write_bytes_per_step": int(kwr),
+                       "dispatches_per_step": round(per_step, 2)}
     tot_rd += krd
     tot_wr += kwr
-res["step_bytes_all_kernels"] = int((tot_rd + tot_wr) / steps)
+res["step_bytes_all_kernels"] = int(tot_rd + tot_wr)
 res["per_kernel"] = per_kernel
 lib = os.environ.get("T360_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transform360_amd", "lib",
                                                  "libTransform360.so")
