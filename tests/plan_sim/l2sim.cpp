@@ -56,6 +56,13 @@ struct SimTile {
 }  // namespace
 
 
+// planner options under study come from the environment of the simulator (never of the library)
+static void sim_options(t360::PlanOptions* o) {
+  if (const char* v = getenv("T360_SIM_WIDE256")) o->wide256_pct = atoi(v);
+  if (const char* v = getenv("T360_SIM_COST_LINES")) o->cost_lines = atoi(v) != 0;
+  if (const char* v = getenv("T360_SIM_WIDE")) o->wide_pct = atoi(v);
+}
+
 static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc, int dhc,
                         int swc, int shc, int ks, int max_pieces, int waves, int order, std::vector<SimTile>* tiles, int* ndirect) {
   using namespace t360;
@@ -66,6 +73,7 @@ static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, 
     o.max_pieces = max_pieces;
     o.waves = waves;
     o.order = order;
+    sim_options(&o);
     if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return false;
   }
   const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
@@ -77,8 +85,8 @@ static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, 
       t.plane = pl;
       const TileDesc& d = p.tiles[(size_t)ti];
       t.ox = d.ox; t.oy = d.oy;
-      t.w = d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
-      t.h = d.kind == kTileStrip128 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
+      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.h = d.kind == kTileStrip128 || d.kind == kTileWide256 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
       const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
       uint32_t prev = ~0u;
       for (int pos = 0; pos < d.pieces * kPieceChunks; pos++)
@@ -145,6 +153,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     o.max_pieces = max_pieces;
     o.waves = waves;
     o.order = order;
+    sim_options(&o);
     if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return -1;
   }
   const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
@@ -157,8 +166,8 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       t.plane = pl;
       const TileDesc& d = p.tiles[(size_t)ti];
       t.ox = d.ox; t.oy = d.oy;
-      t.w = d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
-      t.h = d.kind == kTileStrip128 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
+      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.h = d.kind == kTileStrip128 || d.kind == kTileWide256 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
       const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
       uint32_t prev = ~0u;
       for (int pos = 0; pos < d.pieces * kPieceChunks; pos++)
@@ -198,6 +207,26 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     per_frame_scale = 0.5;  // twice the waves work on it
   }
   const int total = (int)tiles.size();
+  // T360_SIM_NT=1: lines (of one frame) that exactly one tile touches are loaded past the L2 (`nt`: fetched, not kept)
+  const bool sim_nt = getenv("T360_SIM_NT") && atoi(getenv("T360_SIM_NT")) != 0;
+  std::vector<uint8_t> line_users;  // per 128-byte line of one input frame: tiles touching it (saturating)
+  if (sim_nt) {
+    const long long yb = (long long)swy * shy, cb = (long long)swc * shc;
+    line_users.assign((size_t)((yb + 2 * cb) >> 7) + 2, 0);
+    for (const SimTile& t : tiles) {
+      const long long pbase = t.plane == 0 ? 0 : t.plane == 1 ? yb : yb + cb;
+      const int stride = t.plane ? swc : swy;
+      long long prev = -1;
+      std::vector<long long> ls;
+      for (uint32_t e : t.chunks) ls.push_back((pbase + (long long)(e >> 12) * stride + (long long)(e & 4095u) * 16) >> 7);
+      std::sort(ls.begin(), ls.end());
+      for (long long l : ls)
+        if (l != prev) { prev = l; if (line_users[(size_t)l] < 255) line_users[(size_t)l]++; }
+    }
+    long long single = 0, multi = 0;
+    for (uint8_t u : line_users) { single += u == 1; multi += u > 1; }
+    fprintf(stderr, "lines of a frame: %lld touched by one tile, %lld by several\n", single, multi);
+  }
   std::vector<std::vector<int>> neigh((size_t)total);
   for (int i = 0; i < total; i++)
     for (int j = 0; j < total; j++) {
@@ -289,8 +318,14 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       if (lead < 0) front = fr;
       const long long pbase = (long long)fr * frame_in + (t.plane == 0 ? 0 : t.plane == 1 ? ybytes : ybytes + cbytes);
       const int stride = t.plane ? swc : swy;
+      long long prev_nt = -1;
+      const long long fbase = (long long)fr * frame_in;
       for (uint32_t e : t.chunks) {
         const long long a = pbase + (long long)(e >> 12) * stride + (long long)(e & 4095u) * 16;
+        if (sim_nt && line_users[(size_t)((a - fbase) >> 7)] == 1) {
+          if ((a >> 7) != prev_nt) l2.miss++, prev_nt = a >> 7; else l2.hit++;
+          continue;
+        }
         l2.touch((uint64_t)a >> 7, true);
       }
       const long long obase = (long long)fr * frame_out + (t.plane == 0 ? 0 : t.plane == 1 ? oy_bytes : oy_bytes + oc_bytes);

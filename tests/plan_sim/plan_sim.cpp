@@ -22,7 +22,7 @@ extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, 
   t360::HostGatherPlan plan;
   if (!t360::plan_gather(lut, dw, dh, sw, sh, o, &plan)) return 0;
   const t360::PlanStats& s = plan.stats;
-  stats[0] = s.n_strip + s.n_wide128 * 2; stats[1] = s.n_wide; stats[2] = s.n_sq; stats[3] = s.n_16; stats[4] = s.n_direct;
+  stats[0] = s.n_strip + s.n_wide128 * 2 + s.n_wide256 * 2; stats[1] = s.n_wide; stats[2] = s.n_sq; stats[3] = s.n_16; stats[4] = s.n_direct;
   stats[5] = s.fetched_bytes; stats[6] = s.lds_bytes; stats[7] = s.direct_pixels; stats[8] = s.line_bytes;
   stats[9] = (long long)plan.chunks.size() * 4; stats[10] = (long long)plan.tlut.size() * 4;
   int maxp = 0;
@@ -71,7 +71,10 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
   PlanOptions o;
   o.ks = ks;
   o.max_pieces = max_pieces;
-  o.waves = waves;
+  o.waves = waves & 0xff;
+  o.wide256_pct = (waves >> 8) & 0xfff;   // bits 8..19 of `waves`: PlanOptions::wide256_pct
+  o.cost_lines = ((waves >> 20) & 1) != 0;
+  waves &= 0xff;
   HostGatherPlan plan;
   if (!plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
   auto wrapi = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
@@ -108,6 +111,7 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
       case kTileStrip128: w = 128; h = 8; break;
       case kTileWide64: w = 64; h = 16; break;
       case kTileWide128: w = 128; h = 16; lanes = 512; break;
+      case kTileWide256: w = 256; h = 8; lanes = 512; break;
       default: complain("unknown tile kind", ti, t.ox, t.oy); continue;
     }
     for (int tid = 0; tid < lanes; tid++)

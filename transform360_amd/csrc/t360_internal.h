@@ -95,6 +95,8 @@ enum : int {
   kTileStrip128 = 3,  // 128x8 output px, 4 px per lane (2 bands): ~330-byte source row fragments
   kTileWide64 = 4,    // 64x16 output px, 4 px per lane (4 bands)
   kTileWide128 = 5,   // 128x16 output px, 4 px per lane on 512 lanes (4 bands): workgroups of 8 waves only
+  kTileWide256 = 6,   // 256x8 output px, 4 px per lane on 512 lanes (2 bands): workgroups of 8 waves only; ~490-byte
+                      // source row fragments (5 lines for 4 of payload where a 128-wide tile fetches 3 for 2)
 };
 enum : int {
   kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
@@ -144,15 +146,13 @@ constexpr int kBoxMaxRows = 128;        // rows of a box: the row table is 64 dw
 // Chunk table entry: source row (already wrapped) and 16-byte column (already wrapped) of one LDS position.
 inline uint32_t chunk_entry(uint32_t sy, uint32_t cx) { return (sy << 12) | cx; }
 
-// Bicubic weights re-packed for v_dot4: per phase 12 dwords
-//   [0..3]  high bytes (signed)  of the 4 taps of rows 0..3:  w >> 8
-//   [4..7]  low bytes (unsigned) of the 4 taps of rows 0..3:  w & 255
-//   [8]     rounding + bias constant: 16384 + 128*256*SUM(w >> 8)   (pixels are fed as p-128)
-//   [9..11] padding
-constexpr int kCubicPackDwords = 12;
-// dwords per sub-pixel phase of the dot4-packed weight table of a KS x KS interpolation:
-// [KS*WIN signed high-byte dwords][KS*WIN unsigned low-byte dwords][bias][padding to 16 bytes],
-// WIN = 4-byte windows per stencil row (2 for Lanczos4, else 1).  Bilinear fills bytes 0-1 only.
-constexpr int pack_dwords(int ks) { return ks == 2 ? 8 : ks == 4 ? kCubicPackDwords : ks == 8 ? 36 : 0; }
+// Weights re-packed for v_dot4, per sub-pixel phase of a KS x KS interpolation:
+//   [KS*WIN signed high-byte dwords: w >> 8][KS*WIN unsigned low-byte dwords: w & 255]
+// WIN = 4-byte windows per stencil row (2 for Lanczos4, else 1); bilinear fills bytes 0-1 of its window only.
+// Nothing else: 16 / 32 / 128 bytes per phase, a whole number of 16-byte loads.  The bias of the signed half (pixels
+// are fed as p - 128: 128 * SUM(w >> 8)) is recomputed by the kernel from the high bytes (a v_dot4 per dword, once per
+// tile) -- round 4: it used to be a third load per pixel from a 48-byte entry, and the table gather is what a
+// workgroup's prologue waits for (64 distinct entries per load instruction).
+constexpr int pack_dwords(int ks) { return ks == 2 ? 4 : ks == 4 ? 8 : ks == 8 ? 32 : 0; }
 
 }  // namespace t360

@@ -36,6 +36,7 @@ constexpr TileShape kWide{kTileWide64, 64, 16, 4, 256};
 constexpr TileShape kSquare{kTileStaged32, 32, 32, 4, 256};
 constexpr TileShape kSmall{kTileStaged16, 16, 16, 1, 256};
 constexpr TileShape kWide128{kTileWide128, 128, 16, 4, 512};
+constexpr TileShape kWide256{kTileWide256, 256, 8, 4, 512};
 
 inline int floor_div16(int v) { return v >> 4; }  // arithmetic shift: floors negatives too
 inline int wrap(int v, int n) {
@@ -58,6 +59,7 @@ struct Foot {
   int skew = 0;           // LDS bank skew per box row, in chunks (see place())
   int pieces = 0;
   int fetched = 0;        // marked chunks
+  int lines = 0;          // distinct 128-byte source lines among them (what the fabric delivers if nothing is shared)
 };
 
 class Planner {
@@ -116,6 +118,19 @@ class Planner {
       }
     }
     f->fetched = fetched;
+    {
+      int lines = 0;
+      for (int r = 0; r < f->rows; r++) {
+        const uint8_t* m = &f->mask[(size_t)r * f->ncols];
+        int prev_line = -(1 << 30);
+        for (int c = 0; c < f->ncols; c++)
+          if (m[c]) {
+            const int line = (f->c0 + c) >> 3;  // 8 chunks of 16 bytes
+            if (line != prev_line) lines++, prev_line = line;
+          }
+      }
+      f->lines = lines;
+    }
     if (fetched > max_pos_) return;
     f->skew = 0;
     place(f);
@@ -355,20 +370,24 @@ class Planner {
     st.pieces_hist[f.pieces < 32 ? f.pieces : 32]++;
     if (opt_.model_stats && opt_.ks != 1) st.lds_cycles_model += lds_cycles(f);
     (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq
-     : s.kind == kTileWide128 ? st.n_wide128 : st.n_16)++;
+     : s.kind == kTileWide128 ? st.n_wide128 : s.kind == kTileWide256 ? st.n_wide256 : st.n_16)++;
   }
 
-  // the tiles of one 128x32 output region, appended to `out` in execution order
-  void plan_region(int rx, int ry, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
+  // what a tile costs when shapes are compared: the distinct 128-byte lines of its footprint (cost_lines: what the
+  // fabric delivers when no neighbour's fetch of a shared line is still in the L2) or its 16-byte chunks (what is staged)
+  int64_t cost_of(const Foot& f) const { return opt_.cost_lines ? (int64_t)f.lines * 8 : (int64_t)f.fetched; }
+
+  // the tiles of one 128x32 output region at (ox, oy), appended to `pick` in execution order; returns their cost
+  // (infeasible 16x16 tiles -- the direct tiles around the poles -- count as their pixels' stencils read one by one)
+  int64_t choose_region(int ox, int oy, std::vector<Foot>* pick) const {
     const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
     const bool wide_ok = !only16 && opt_.wide_pct > 0 && opt_.ks != 1;  // nearest has no halo to share
     const bool strip_ok = !only16 && opt_.strip_pct > 0;
     Foot strip[4], wide[2], sq[4], small;
-    const int ox = rx * 128, oy = ry * 32;
     // squares first (always evaluated: they are the fallback), then the wider shapes
     auto cost_sq = [&](int k, bool* all_staged) -> int64_t {
       if (sq[k].empty) return 0;
-      if (sq[k].feasible) return (int64_t)sq[k].fetched;
+      if (sq[k].feasible) return cost_of(sq[k]);
       *all_staged = false;
       return (int64_t)1 << 40;
     };
@@ -388,11 +407,11 @@ class Planner {
       int64_t cq = 0;
       for (int k = 0; k < 4; k++) cq += cost_sq(k, &sq_ok);
       const bool bf = !big[0].empty && big[0].feasible && (big[1].empty || big[1].feasible);
-      const int64_t cb = (big[0].empty ? 0 : big[0].fetched) + (big[1].empty ? 0 : big[1].fetched);
+      const int64_t cb = (big[0].empty ? 0 : cost_of(big[0])) + (big[1].empty ? 0 : cost_of(big[1]));
       if (bf && (!sq_ok || cb * 100 <= cq * opt_.wide_pct)) {
-        emit(big[0], out, direct);
-        if (!big[1].empty) emit(big[1], out, direct);
-        return;
+        pick->push_back(big[0]);
+        if (!big[1].empty) pick->push_back(big[1]);
+        return cb;
       }
     }
     if (strip_ok) {
@@ -402,16 +421,17 @@ class Planner {
         footprint(ox, oy + 8 * k, kStrip, &strip[k]);
         if (!strip[k].empty) {
           ok = ok && strip[k].feasible;
-          cs += strip[k].fetched;
+          cs += cost_of(strip[k]);
         }
         cq += cost_sq(k, &sq_ok);
       }
       if (ok && (!sq_ok || cs * 100 <= cq * opt_.strip_pct)) {
         for (int k = 0; k < 4; k++)
-          if (!strip[k].empty) emit(strip[k], out, direct);
-        return;
+          if (!strip[k].empty) pick->push_back(strip[k]);
+        return cs;
       }
     }
+    int64_t total = 0;
     for (int h = 0; h < 2; h++) {
       if (wide_ok && !sq[2 * h].empty && !sq[2 * h + 1].empty) {
         footprint(ox + 64 * h, oy, kWide, &wide[0]);
@@ -419,29 +439,70 @@ class Planner {
         const bool wf = (wide[0].empty || wide[0].feasible) && (wide[1].empty || wide[1].feasible) && !wide[0].empty;
         bool sq_ok = true;
         const int64_t cq = cost_sq(2 * h, &sq_ok) + cost_sq(2 * h + 1, &sq_ok);
-        const int64_t cw = (wide[0].empty ? 0 : wide[0].fetched) + (wide[1].empty ? 0 : wide[1].fetched);
+        const int64_t cw = (wide[0].empty ? 0 : cost_of(wide[0])) + (wide[1].empty ? 0 : cost_of(wide[1]));
         if (wf && (!sq_ok || cw * 100 <= cq * opt_.wide_pct)) {
-          if (!wide[0].empty) emit(wide[0], out, direct);
-          if (!wide[1].empty) emit(wide[1], out, direct);
+          if (!wide[0].empty) pick->push_back(wide[0]);
+          if (!wide[1].empty) pick->push_back(wide[1]);
+          total += cw;
           continue;
         }
       }
       for (int k = 2 * h; k < 2 * h + 2; k++) {
         if (sq[k].empty) continue;
         if (sq[k].feasible) {
-          emit(sq[k], out, direct);
+          pick->push_back(sq[k]);
+          total += cost_of(sq[k]);
           continue;
         }
         for (int qd = 0; qd < 4; qd++) {
           footprint(ox + 32 * k + (qd & 1) * 16, oy + (qd >> 1) * 16, kSmall, &small);
-          if (!small.empty) emit(small, out, direct);  // staged 16x16 or direct
+          if (small.empty) continue;
+          pick->push_back(small);  // staged 16x16 or direct
+          total += small.feasible ? cost_of(small) : (int64_t)256 * opt_.ks * 8;
         }
       }
     }
+    return total;
   }
 
+  // One planning region: 128x32 output px, or -- with PlanOptions::wide256_pct > 0 and workgroups of 8 waves -- 256x32,
+  // where four 256x8 tiles replace the two 128x32 halves' tiles when they cost no more than wide256_pct % of them.
+  // A 256-px-wide tile fetches ~490-byte row fragments: 5 lines for 4 of payload, where a 128-px-wide one fetches 3
+  // for 2 -- and most of the ragged line ends of neighbouring tiles are fetched twice in practice, because
+  // neighbouring workgroups drift apart in frame number.
+  void plan_region(int rx, int ry, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
+    std::vector<Foot> pick;
+    const int rw = region_w();
+    const int ox = rx * rw, oy = ry * 32;
+    if (rw == 256) {
+      std::vector<Foot> halves;
+      int64_t ch = choose_region(ox, oy, &halves);
+      if (ox + 128 < dw_) ch += choose_region(ox + 128, oy, &halves);
+      Foot w256[4];
+      bool ok = true;
+      int64_t cw = 0;
+      for (int k = 0; k < 4 && ok; k++) {
+        footprint(ox, oy + 8 * k, kWide256, &w256[k]);
+        if (w256[k].empty) continue;
+        ok = w256[k].feasible;
+        cw += cost_of(w256[k]);
+      }
+      if (ok && !w256[0].empty && cw * 100 <= ch * opt_.wide256_pct) {
+        for (int k = 0; k < 4; k++)
+          if (!w256[k].empty) pick.push_back(w256[k]);
+      } else {
+        pick.swap(halves);
+      }
+    } else {
+      choose_region(ox, oy, &pick);
+    }
+    for (Foot& f : pick) emit(f, out, direct);
+  }
+  int region_w() const { return (opt_.waves == 8 && opt_.wide256_pct > 0 && opt_.ks != 8 && opt_.ks != 1) ? 256 : 128; }
+
+
   bool run(HostGatherPlan* out) const {
-    const int regions_x = (dw_ + 127) / 128, regions_y = (dh_ + 31) / 32;
+    const int regions_x = (dw_ + region_w() - 1) / region_w(), regions_y = (dh_ + 31) / 32;
     const int band = std::max(1, opt_.band);
     // Emission order = execution order.  raster = false: region rows are walked in bands, column by column inside
     // a band, so that vertically adjacent tiles -- whose footprints share the stencil halo and the rows a curved
@@ -496,7 +557,7 @@ class Planner {
       PlanStats& a = out->stats;
       const PlanStats& b = p.stats;
       a.n_strip += b.n_strip; a.n_wide += b.n_wide; a.n_sq += b.n_sq; a.n_16 += b.n_16; a.n_direct += b.n_direct;
-      a.n_wide128 += b.n_wide128;
+      a.n_wide128 += b.n_wide128; a.n_wide256 += b.n_wide256;
       a.fetched_bytes += b.fetched_bytes; a.lds_bytes += b.lds_bytes; a.direct_pixels += b.direct_pixels;
       a.lds_cycles_model += b.lds_cycles_model;
       a.line_bytes += b.line_bytes;
@@ -601,7 +662,6 @@ void pack_weights(const std::vector<int16_t>& tab, int ks, std::vector<uint32_t>
   for (int f = 0; f < phases; f++) {
     const int16_t* w = &tab[(size_t)f * ks * ks];
     uint32_t* o = &(*out)[(size_t)f * stride];
-    int sum_hi = 0;
     for (int r = 0; r < ks; r++)
       for (int q = 0; q < win; q++) {
         uint32_t hi = 0, lo = 0;
@@ -611,15 +671,14 @@ void pack_weights(const std::vector<int16_t>& tab, int ks, std::vector<uint32_t>
           const int v = w[r * ks + tap];
           const int h = v >> 8;   // arithmetic shift: floor, in [-128, 127]
           const int l = v & 255;  // v == h * 256 + l
-          sum_hi += h;
           hi |= (uint32_t)(h & 255) << (8 * c);
           lo |= (uint32_t)l << (8 * c);
         }
         o[r * win + q] = hi;
         o[nw + r * win + q] = lo;
       }
-    // pixels enter the signed part as p - 128:  SUM p*w = 256 * (SUM (p-128)*wh + 128 * SUM wh) + SUM p*wl
-    o[2 * nw] = (uint32_t)(128 * sum_hi);
+    // (pixels enter the signed part as p - 128:  SUM p*w = 256 * (SUM (p-128)*wh + 128 * SUM wh) + SUM p*wl; the kernel
+    // derives 128 * SUM wh from the high bytes)
   }
 }
 

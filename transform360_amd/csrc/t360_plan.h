@@ -18,6 +18,9 @@ struct PlanOptions {
   int max_pieces = 12;   // largest staged region of one tile, in 1 KiB DMA pieces (<= kMaxPieces)
   int wide_pct = 200;    // 64x16 tiles replace a pair of 32x32 tiles unless they fetch more than this % of the pair
   int strip_pct = 0;     // > 0: 128x8 strips replace the region's other tiles when they fetch <= this % of them
+  int wide256_pct = 0;   // > 0 (workgroups of 8 waves): four 256x8 tiles replace a 256x32 region's other tiles when they
+                         // cost <= this % of them
+  bool cost_lines = false;  // shapes are compared by the distinct 128-byte lines of their footprints, not by chunks
   int band = 4;          // order 0: region rows walked column by column (execution order, see t360_plan.cpp)
   int order = 2;         // execution order of the tiles: 0 bands of region rows (below), 1 raster, 2 Z-order of 64x16 cells
   int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
@@ -30,7 +33,7 @@ struct PlanOptions {
 };
 
 struct PlanStats {
-  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0, n_wide128 = 0;
+  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0, n_wide128 = 0, n_wide256 = 0;
   int64_t fetched_bytes = 0;   // distinct source chunks fetched per frame x 16 (HBM/L2 -> LDS, one copy)
   int64_t lds_bytes = 0;       // LDS positions per frame x 16 (incl. holes), one copy
   int64_t direct_pixels = 0;

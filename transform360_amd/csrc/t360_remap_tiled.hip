@@ -69,6 +69,16 @@ constexpr bool dual_copy(int ks) { return T360_DUAL != 0 && ks != 1; }
 #ifndef T360_ASMREAD
 #define T360_ASMREAD 1
 #endif
+// T360_B64M: 1 = a stencil-row window is ONE ds_read_b64 at the 4-byte-aligned address below it (addresses that are
+// 4 mod 8 included; tools/ubench/lds_b64_align4.hip), 0 = two ds_read_b32
+#ifndef T360_B64M
+#define T360_B64M 0
+#endif
+// T360_DMA_FIRST: 1 = the first frames' DMA is issued before the weight gather of the prologue (round 4: 0.2498 ->
+// 0.2427 ms per 64-frame launch on the same box; tools/experiments_r04/call1.sh)
+#ifndef T360_DMA_FIRST
+#define T360_DMA_FIRST 1
+#endif
 template <int P, bool DUAL>
 struct Slot {
   // copy B: the same bytes 4 further (odd dwords become 8-byte aligned) and half a bank row (32 dwords) apart,
@@ -166,7 +176,7 @@ __device__ __forceinline__ void load_pixels(const TileFetch& tf, const uint32_t*
     }
     s.hb[p] = 0;
     if (NW > 0) {
-      // [NW high dwords][NW low dwords][128 * SUM(wh)], 16-byte aligned: 2*NW/4 vector loads + 1
+      // [NW high dwords][NW low dwords], 16-byte aligned: 2*NW/4 vector loads
       const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(wpack + (size_t)frac * Stencil<KS>::PACK);
       uint32_t w[2 * (NW > 0 ? NW : 2)];
 #pragma unroll
@@ -174,12 +184,15 @@ __device__ __forceinline__ void load_pixels(const TileFetch& tf, const uint32_t*
         const uint4 v = wp[k];
         w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
       }
+      // 128 * SUM(signed high bytes): the bias of the signed half of the products (pixels enter it as p - 128)
+      int sum_hi = 0;
 #pragma unroll
       for (int k = 0; k < NW; k++) {
         s.wh[p][k] = w[k];
         s.wl[p][k] = w[NW + k];
+        sum_hi = __builtin_amdgcn_sdot4((int)w[k], 0x01010101, sum_hi, false);
       }
-      s.hb[p] = (int)wpack[(size_t)frac * Stencil<KS>::PACK + 2 * NW];
+      s.hb[p] = 128 * sum_hi;
     }
   }
 }
@@ -355,11 +368,15 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
           } else if (T360_ASMREAD && WIN == 1) {
             // the ring slot as the IMMEDIATE offset of two ds_read_b32 (16 bits; ds_read2_b32 has 8-bit offsets, so for
             // slots 1.. hipcc adds the slot base to every address register first: 16 VALU per 4 pixels and frame)
-            uint32_t d0, d1;
             const uint32_t la = (uint32_t)(uintptr_t)lds + s.addr[p0 + p][r];  // loop invariant: hoisted out of the frame loop
+#if T360_B64M
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(win[p][r]) : "v"(la), "n"(SLOT));
+#else
+            uint32_t d0, d1;
             asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d0) : "v"(la), "n"(SLOT));
             asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d1) : "v"(la), "n"(SLOT + 4));
             win[p][r] = (uint64_t)d0 | ((uint64_t)d1 << 32);
+#endif
           } else {
             // two aligned dwords (the slot base does not fit ds_read2_b32's 8-bit offsets: two ds_read_b32)
             const uint32_t d0 = *reinterpret_cast<const uint32_t*>(lds + s.addr[p0 + p][r] + SLOT);
@@ -447,7 +464,7 @@ __device__ __forceinline__ uint32_t out_pos(const TiledPlane& pl, const TileDesc
   const int tid = threadIdx.x;
   int ox, oy;
   if (NPX == 4) {
-    const int logw = (t.kind == kTileStrip128 || t.kind == kTileWide128) ? 7 : (t.kind == kTileWide64 ? 6 : 5);
+    const int logw = t.kind == kTileWide256 ? 8 : (t.kind == kTileStrip128 || t.kind == kTileWide128) ? 7 : (t.kind == kTileWide64 ? 6 : 5);
     const int x = tid & ((1 << logw) - 1), band = tid >> logw;
     if (dword_store) {
       ox = t.ox + (x & ~3);
@@ -560,7 +577,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   (void)lane;
   const int mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;  // my pieces: wave, wave + WAVES, ... (0..4 of them)
   // does this wave hold pixels?  (a 256-lane tile in a workgroup of 8 waves: waves 4..7 only move bytes)
-  const bool has_px = WAVES == 4 || t.kind == kTileWide128 || wave < 4;
+  const bool has_px = WAVES == 4 || t.kind == kTileWide128 || t.kind == kTileWide256 || wave < 4;
   // chunk q = lane + 64*piece lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
   // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
   int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4's order)
@@ -573,7 +590,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds + (uint32_t)wave * 1024u;
   auto issue = [&](int f, int slot_bytes) {
     if (mine <= 0) return;
-    const uint8_t* base = T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)f * pl.src_frame_bytes));
+    const uint8_t* base = T360_UNIFORM(const_cast<uint8_t*>(pl.src + (size_t)(T360_DBG(a, 6) ? 0 : f) * pl.src_frame_bytes));
     dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, WAVES * 1024u, goff);
     if (DUAL && !T360_DBG(a, 5)) dma_frame_4(mine, base, lds_base + (uint32_t)(slot_bytes + R::kCopyB), WAVES * 1024u, goff);
   };
@@ -582,10 +599,20 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   T360_MARK(a, 1);  // tile tables here
   // weights first (they depend on the pixel words only), then the prologue DMA, then wait for both
   PixelSetup<NPX, KS> px;
+#if T360_DMA_FIRST
+  // the first frames' DMA goes out BEFORE the weight gather: the vector memory pipe is in order, and the 12 table loads
+  // per lane of load_pixels() keep its front end busy for ~3 us (64 distinct lines per instruction) -- queued behind
+  // them, the DMA requests left only then and their ~2 us of HBM latency came on top
+#pragma unroll
+  for (int j = 0; j < K - 1; j++)
+    if (j < nf) issue(f0 + j, j * R::kSlot);
+  load_pixels<NPX, KS, P>(tf, a.wpack, px);
+#else
   load_pixels<NPX, KS, P>(tf, a.wpack, px);
 #pragma unroll
   for (int j = 0; j < K - 1; j++)
     if (j < nf) issue(f0 + j, j * R::kSlot);
+#endif
   pin_pixels<NPX, KS>(px);
   T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
   const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
@@ -612,10 +639,10 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
       T360_PHASE(4);                                                                                       \
       wait_vmcnt(min(K - 2, nf - 1 - (i + S)) * per_frame); /* my loads younger than this frame's */       \
       T360_PHASE(0);                                                                                       \
-      frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */     \
+      if (!T360_DBG(a, 7)) frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */ \
       T360_PHASE(1);                                                                                       \
       if (i + S > 0) {                                                                                     \
-        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);                          \
+        if (has_px && !T360_DBG(a, 8)) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);       \
         d += pl.dst_frame_bytes;                                                                           \
       }                                                                                                    \
       if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \

@@ -198,6 +198,8 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_TAIL_FRAMES")) tail_frames_ = atoi(e);
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
+  if (const char* e = getenv("T360_WIDE256")) plan_wide256_pct_ = atoi(e);
+  if (const char* e = getenv("T360_COST_LINES")) plan_cost_lines_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
   if (const char* e = getenv("T360_ROW_PAD")) plan_row_pad_ = atoi(e);
   if (const char* e = getenv("T360_ROW_ALIGN")) plan_row_align_ = atoi(e);
@@ -1224,6 +1226,8 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   o.max_pieces = max_pieces;
   o.wide_pct = plan_wide_pct_;
   o.strip_pct = plan_strip_pct_;
+  o.wide256_pct = small ? 0 : plan_wide256_pct_;
+  o.cost_lines = plan_cost_lines_ != 0;
   o.band = plan_band_ > 0 ? plan_band_ : 4;
   o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
   o.row_pad = plan_row_pad_;
