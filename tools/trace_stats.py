@@ -15,7 +15,7 @@ xcc = (a[:, 7] >> np.uint64(32)).astype(int)
 hw = (a[:, 7] & np.uint64(0xffffffff)).astype(int)
 cu = xcc * 65536 + (hw & 0xff00)
 print("workgroups traced: %d, kernel span %.1f us" % (len(a), T[:, 5].max()))
-for k, name in ((4, "64x16"), (0, "32x32"), (3, "128x8"), (1, "16x16")):
+for k, name in ((5, "128x16"), (6, "256x8"), (4, "64x16"), (0, "32x32"), (3, "128x8"), (1, "16x16")):
     m = (kind == k) & (T[:, 5] > 0)
     if not m.any():
         continue
