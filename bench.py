@@ -278,6 +278,23 @@ class HipPath:
     def seed_of(self, j):
         return self.handler.frame_seed(self.rank * self.F + j)
 
+    def second_handle(self):
+        """a second handle on its own stream with its own output buffer: consecutive steps of a frame stream are
+        independent, and alternating them between two handles lets step k+1 start while step k drains"""
+        if getattr(self, "t2", None) is None:
+            self.stream2 = self.torch.cuda.Stream()
+            self.t2 = self.handler.VideoFrameTransform(self.ctx)
+            for idx, k in ((0, 0), (1, 1)):
+                assert self.t2.generateMapForPlane(*self.lin.dims[k], *self.lout.dims[k], idx)
+            assert self.t2.setStream(self.stream2)
+            self.d_out2 = self.torch.zeros_like(self.d_out)
+        return self.t2
+
+    def step2(self, n_frames, inp=None):
+        """the same step on the second handle / stream / output buffer"""
+        assert self.second_handle().transformFrames(self.d_in if inp is None else inp, self.lin.frame_bytes, self.d_out2,
+                                                    self.lout.frame_bytes, n_frames, self.descs)
+
     def step(self, n_frames, events=None, out=None, inp=None):
         # one call = all three planes of n_frames frames; ONE fused launch of the tiled gather kernel
         # (plus the low-pass launches for config 3)
@@ -330,6 +347,8 @@ class HipPath:
 
     def close(self):
         self.t.close()
+        if getattr(self, "t2", None) is not None:
+            self.t2.close()
 
 
 class StubPath:
@@ -462,7 +481,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             dist.barrier()
             path.sync()
 
-    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False, before_step=None):
+    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False, before_step=None, alternate=False):
         """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms]).
         rotate: step k reads the k-th group of n_frames input frames of this rank's F (a short step must not find its
         input in the 256 MB Infinity Cache just because every step reads the same few frames)."""
@@ -483,8 +502,11 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 path.k = k  # the double-buffered legs pick their buffers from the step number of THIS timed region
                 if before_step is not None:
                     before_step(k)
-                if ring is not None:
-                    path.step(n_frames, inp=ring[(k % groups) * n_frames * lin.frame_bytes:])
+                inp = ring[(k % groups) * n_frames * lin.frame_bytes:] if ring is not None else None
+                if alternate and (k & 1):
+                    path.step2(n_frames, inp=inp)
+                elif inp is not None:
+                    path.step(n_frames, inp=inp)
                 else:
                     path.step(n_frames)
                 if after_step is not None:
@@ -558,8 +580,48 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             c_el = sorted(r[0] for r in cruns)[len(cruns) // 2]
             strong["input"] = "every step reads other frames of the rank's %d-frame ring (HBM)" % (getattr(path, "groups", 1) * F)
             strong["ms_per_step_same_input_every_step"] = round(c_el / args.steps * 1e3, 4)
+        if path.name == "hip":
+            # The same steps alternating between TWO handles on two streams (two output buffers): a frame stream's
+            # consecutive batches are independent, so step k+1's workgroups start while step k's last ones drain
+            # (VERDICT round 3, item 2).  A second figure, next to the one-stream one above.
+            path.second_handle()
+            for k in range(4):
+                (path.step2 if k & 1 else path.step)(f5)
+            pruns = timed_run(f5, args.steps, False, rotate=rotate, alternate=True)
+            p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
+            strong["two_streams"] = {"what": "steps alternate between two handles on two HIP streams (independent batches, two output buffers)",
+                                     "ms_per_step": round(p_el / args.steps * 1e3, 4),
+                                     "value": round(min(64, f5 * world) * args.steps / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s"}
+        if world == 1 and F >= 64 and path.name == "hip":
+            # what ONE GPU of an 8-GPU node runs for configs[4]: 8 of the 64 frames per step.  Timed here on one GPU (input
+            # rotating through the ring, so from HBM): the projected strong-scaling factor is t(64 frames) / t(8 frames).
+            warm_steps(8, max(2, args.warmup))
+            e8 = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate))[REPEATS // 2]
+            for k in range(4):
+                (path.step2 if k & 1 else path.step)(8)
+            e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, alternate=True))[REPEATS // 2]
+            strong["projected_8_gpus"] = {
+                "frames_per_gpu": 8, "ms_per_step": round(e8 / args.steps * 1e3, 4),
+                "speedup_over_1_gpu": round(s_el / e8, 2),
+                "two_streams_ms_per_step": round(e8p / args.steps * 1e3, 4),
+                "two_streams_speedup_over_1_gpu": round(s_el / e8p, 2),
+                "what": "one GPU's share at 8 GPUs (8 frames per step) timed on this GPU; speedup = this line's 64-frame step time / "
+                        "the 8-frame step time (no inter-GPU traffic on the path: frames are sharded, SURVEY 8e)"}
         if f5 * world != 64:
             strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
+
+    pipelined = None
+    if args.config == 2 and path.name == "hip" and world == 1:
+        path.second_handle()
+        for k in range(4):
+            (path.step2 if k & 1 else path.step)(F)
+        pruns = timed_run(F, args.steps, False, rotate=rotate, alternate=True)
+        p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
+        pipelined = {"what": "the headline steps alternating between two handles on two HIP streams (independent batches, two "
+                             "output buffers): step k+1 starts while step k drains; NOT the `value` above, whose launches are "
+                             "back to back on one stream",
+                     "ms_per_step": round(p_el / args.steps * 1e3, 4),
+                     "value": round(args.steps * F * world / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s"}
 
     # the same steps with every step's output frames gathered to rank 0 (RCCL gather over xGMI; a
     # device copy when there is one rank), overlapped with the next step: outputs alternate between two buffers and a
@@ -743,6 +805,8 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         }
         if strong is not None:
             res["strong_cfg5"] = strong
+        if pipelined is not None:
+            res["two_streams"] = pipelined
         if gathered is not None:
             res["gather_outputs"] = gathered
         if scattered is not None:

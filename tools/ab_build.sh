@@ -7,12 +7,12 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/transform360_amd/csrc
 O=$R/tools/ab/$NAME
 mkdir -p "$O"
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -I$R/include -I$S -DT360_INSTRUMENT $*"
+FL=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -I$R/include -I$S -DT360_INSTRUMENT "$@")
 for f in t360_mapgen.hip t360_remap.hip t360_remap_tiled.hip t360_lowpass.hip t360_resize.hip; do
-  /opt/rocm/bin/hipcc $FL -c $S/$f -o $O/${f%.hip}.o &
+  /opt/rocm/bin/hipcc "${FL[@]}" -c $S/$f -o $O/${f%.hip}.o &
 done
 for f in t360_filtercfg.cpp t360_plan.cpp t360_hoststage.cpp t360_transform.cpp t360_capi.cpp; do
-  /opt/rocm/bin/hipcc $FL -x hip -c $S/$f -o $O/${f%.cpp}.o &
+  /opt/rocm/bin/hipcc "${FL[@]}" -x hip -c $S/$f -o $O/${f%.cpp}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -Wl,-rpath,/opt/rocm/lib -o $R/tools/ab/libT360_$NAME.so $O/*.o

@@ -525,7 +525,10 @@ __device__ __forceinline__ void dma_frame_4(int nj, const uint8_t* frame_base, u
                                             const int (&off)[4]) {
   const uint32_t skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)(12u + 16u * (uint32_t)(4 - nj)));
   const uint32_t m0_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_dst + (uint32_t)(nj - 1) * lds_step));
-#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %4\n\ts_sub_u32 m0, m0, %7\n\ts_nop 0\n\t"
+#ifndef T360_DMA_POLICY
+#define T360_DMA_POLICY ""  // cache policy bits of the staging loads ("" | " sc1" | " sc0 sc1" | " nt"): A/B builds only
+#endif
+#define T360_DMA(k) "global_load_lds_dwordx4 %" #k ", %4" T360_DMA_POLICY "\n\ts_sub_u32 m0, m0, %7\n\ts_nop 0\n\t"
   asm volatile(
       "s_mov_b32 m0, %5\n\t"
       "s_getpc_b64 vcc\n\t"
@@ -877,8 +880,16 @@ hipError_t launch_one(const TiledArgs& a, int groups, hipStream_t stream) {
   const int per_xcd = (a.total_tiles + 7) / 8;
   const int tail = (per_xcd * a.tail_percent) / 100;
   const int items = (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;  // >= any XCD's item count
+  size_t lds_request = (size_t)lds_bytes;
+#ifdef T360_INSTRUMENT
+  if (a.lds_pad > 0) {  // occupancy experiments: ask for more LDS than the ring needs (fewer workgroups per CU)
+    lds_request += (size_t)a.lds_pad;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(remap_tiled_kernel<KS, RINGKB, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
+  }
+#endif
   hipLaunchKernelGGL((remap_tiled_kernel<KS, RINGKB, WAVES>), dim3(a.direct_blocks + 8 * items, 1, 1), dim3(64 * WAVES),
-                     (size_t)lds_bytes, stream, a);
+                     lds_request, stream, a);
   return hipGetLastError();
 }
 

@@ -1054,6 +1054,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.waves = fused.ks == 8 || small ? 4 : waves_;
 #ifdef T360_INSTRUMENT
     fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
+    fused.lds_pad = getenv("T360_LDS_PAD") ? atoi(getenv("T360_LDS_PAD")) : 0;
 #endif
   };
   auto flush_fused = [&]() -> bool {
