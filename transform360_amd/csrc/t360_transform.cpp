@@ -1026,7 +1026,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // (up to 4 planes each: Y, U and V of a yuv420p batch are ONE launch); everything else -- BARREL outputs
   // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
   // which of the two plans: every plane of the call must have the one that is used
-  bool small = small_batch_ > 0 && n_frames < small_batch_ && interp != LANCZOS4 && waves_ != 4;
+  // (nearest-neighbour plans hold 256-lane tiles only -- a pixel has no stencil halo to share with a wider tile -- so half
+  // the waves of an 8-wave workgroup would carry no pixels: 4-wave workgroups, four to a CU, at every batch length;
+  // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, tools/experiments_r04/call8.sh)
+  bool small = small_batch_ > 0 && (n_frames < small_batch_ || interp == NEAREST) && interp != LANCZOS4 && waves_ != 4;
   for (int k = 0; k < njobs; k++)
     if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], small)) return false;
   // (a map the 4-wave planner could not take but the 8-wave one can: every plane of the call then uses the latter)
