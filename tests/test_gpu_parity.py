@@ -379,6 +379,8 @@ VARIANTS = [
     {"T360_WIDE64": "1000"}, {"T360_BAND": "1"}, {"T360_ROW_PAD": "2"}, {"T360_FRAMES_PER_BLOCK": "2"},
     {"T360_FRAMES_PER_BLOCK": "3", "T360_WAVES": "4", "T360_RING_KB": "31", "T360_MAX_PIECES": "8"}, {"T360_NO_TILED": "1"}, {"T360_NO_FAST_LOWPASS": "1"},
     {"T360_NO_WIDE_LOWPASS": "1"}, {"T360_SMALL_BATCH": "1000"},
+    # round 4: 256x8 tiles (kTileWide256) wherever they fit / where they touch fewer lines; extra LDS per workgroup
+    {"T360_WIDE256": "1000"}, {"T360_WIDE256": "100", "T360_COST_LINES": "1"}, {"T360_LDS_PAD": "8192"},
 ]
 
 
