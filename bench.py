@@ -27,6 +27,11 @@ BASELINE.json configs[4] as written: 64 frames in total, ceil(64/N) per rank (no
 Everything a rank does is run_rank(); `--stub` runs that same function with a CPU stand-in for the transform under
 gloo (tests/test_host_cpu.py: the code the 8-GPU run executes is the code the CPU test covers).
 
+Extra records of the default line (one GPU, config 2): "strong_cfg5.projected_8_gpus" = what one GPU of an 8-GPU node runs for
+configs[4] (8 frames per step) timed on this GPU, and "two_streams" = the same steps alternating between two handles on two
+HIP streams (independent batches; the tail of one launch overlaps the start of the next).  Neither enters `value`;
+--no-two-streams leaves the overlapped launches out (kernel traces).
+
 Rank 0 prints ONE JSON line:
   value        = frames/s (whole job) x output luma pixels / 1e6                              [Mpix/s]
   roofline     = algorithmic bytes of the step's kernel launch / its average duration (HIP events on the launch
@@ -580,7 +585,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             c_el = sorted(r[0] for r in cruns)[len(cruns) // 2]
             strong["input"] = "every step reads other frames of the rank's %d-frame ring (HBM)" % (getattr(path, "groups", 1) * F)
             strong["ms_per_step_same_input_every_step"] = round(c_el / args.steps * 1e3, 4)
-        if path.name == "hip":
+        if path.name == "hip" and not args.no_two_streams:
             # The same steps alternating between TWO handles on two streams (two output buffers): a frame stream's
             # consecutive batches are independent, so step k+1's workgroups start while step k's last ones drain
             # (VERDICT round 3, item 2).  A second figure, next to the one-stream one above.
@@ -597,21 +602,22 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             # rotating through the ring, so from HBM): the projected strong-scaling factor is t(64 frames) / t(8 frames).
             warm_steps(8, max(2, args.warmup))
             e8 = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate))[REPEATS // 2]
-            for k in range(4):
-                (path.step2 if k & 1 else path.step)(8)
-            e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, alternate=True))[REPEATS // 2]
             strong["projected_8_gpus"] = {
                 "frames_per_gpu": 8, "ms_per_step": round(e8 / args.steps * 1e3, 4),
                 "speedup_over_1_gpu": round(s_el / e8, 2),
-                "two_streams_ms_per_step": round(e8p / args.steps * 1e3, 4),
-                "two_streams_speedup_over_1_gpu": round(s_el / e8p, 2),
                 "what": "one GPU's share at 8 GPUs (8 frames per step) timed on this GPU; speedup = this line's 64-frame step time / "
                         "the 8-frame step time (no inter-GPU traffic on the path: frames are sharded, SURVEY 8e)"}
+            if not args.no_two_streams:
+                for k in range(4):
+                    (path.step2 if k & 1 else path.step)(8)
+                e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, alternate=True))[REPEATS // 2]
+                strong["projected_8_gpus"]["two_streams_ms_per_step"] = round(e8p / args.steps * 1e3, 4)
+                strong["projected_8_gpus"]["two_streams_speedup_over_1_gpu"] = round(s_el / e8p, 2)
         if f5 * world != 64:
             strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
 
     pipelined = None
-    if args.config == 2 and path.name == "hip" and world == 1:
+    if args.config == 2 and path.name == "hip" and world == 1 and not args.no_two_streams:
         path.second_handle()
         for k in range(4):
             (path.step2 if k & 1 else path.step)(F)
@@ -829,6 +835,9 @@ def main():
                     help="also time the steps with every step's output frames gathered to rank 0, overlapped with the next step")
     ap.add_argument("--scatter-inputs", action="store_true",
                     help="also time the steps with the inputs scattered from rank 0 and the outputs gathered to it, overlapped")
+    ap.add_argument("--no-two-streams", action="store_true",
+                    help="skip the legs that alternate steps between two handles on two streams (kernel traces: overlapped "
+                         "launches of the hot kernel would enter its average duration)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
     args = ap.parse_args()
