@@ -61,6 +61,7 @@ static void sim_options(t360::PlanOptions* o) {
   if (const char* v = getenv("T360_SIM_WIDE256")) o->wide256_pct = atoi(v);
   if (const char* v = getenv("T360_SIM_COST_LINES")) o->cost_lines = atoi(v) != 0;
   if (const char* v = getenv("T360_SIM_WIDE")) o->wide_pct = atoi(v);
+  if (const char* v = getenv("T360_SIM_SCATTER")) o->scatter = atoi(v);
 }
 
 static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc, int dhc,
@@ -76,7 +77,7 @@ static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, 
     sim_options(&o);
     if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return false;
   }
-  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces, plan[0].scatter);
   *ndirect = plan[0].ndirect + 2 * plan[1].ndirect;
   for (int pl = 0; pl < 3; pl++) {
     const HostGatherPlan& p = plan[pl ? 1 : 0];
@@ -85,7 +86,7 @@ static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, 
       t.plane = pl;
       const TileDesc& d = p.tiles[(size_t)ti];
       t.ox = d.ox; t.oy = d.oy;
-      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 || d.kind == kTileScatter ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
       t.h = d.kind == kTileStrip128 || d.kind == kTileWide256 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
       const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
       uint32_t prev = ~0u;
@@ -156,7 +157,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     sim_options(&o);
     if (!plan_gather(k ? lut_c : lut_y, k ? dwc : dwy, k ? dhc : dhy, k ? swc : swy, k ? shc : shy, o, &plan[k])) return -1;
   }
-  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces, plan[0].scatter);
   std::vector<SimTile> tiles;
   long long staged_chunks = 0;
   for (int pl = 0; pl < 3; pl++) {
@@ -166,7 +167,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       t.plane = pl;
       const TileDesc& d = p.tiles[(size_t)ti];
       t.ox = d.ox; t.oy = d.oy;
-      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
+      t.w = d.kind == kTileWide256 ? 256 : d.kind == kTileWide128 || d.kind == kTileStrip128 || d.kind == kTileScatter ? 128 : d.kind == kTileWide64 ? 64 : d.kind == kTileStaged32 ? 32 : 16;
       t.h = d.kind == kTileStrip128 || d.kind == kTileWide256 ? 8 : d.kind == kTileStaged32 ? 32 : 16;
       const uint32_t* tc = &p.chunks[(size_t)ti * cstride];
       uint32_t prev = ~0u;
@@ -209,6 +210,7 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
   const int total = (int)tiles.size();
   // T360_SIM_NT=1: lines (of one frame) that exactly one tile touches are loaded past the L2 (`nt`: fetched, not kept)
   const bool sim_nt = getenv("T360_SIM_NT") && atoi(getenv("T360_SIM_NT")) != 0;
+  const int sim_block = getenv("T360_SIM_BLOCK") ? atoi(getenv("T360_SIM_BLOCK")) : 0;
   std::vector<uint8_t> line_users;  // per 128-byte line of one input frame: tiles touching it (saturating)
   if (sim_nt) {
     const long long yb = (long long)swy * shy, cb = (long long)swc * shc;
@@ -321,7 +323,12 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       long long prev_nt = -1;
       const long long fbase = (long long)fr * frame_in;
       for (uint32_t e : t.chunks) {
-        const long long a = pbase + (long long)(e >> 12) * stride + (long long)(e & 4095u) * 16;
+        long long a = pbase + (long long)(e >> 12) * stride + (long long)(e & 4095u) * 16;
+        if (sim_block > 0) {
+          // T360_SIM_BLOCK=h: the plane stored in blocks of (128 / h) x h pixels (one 128-byte line each) instead of rows
+          const long long row = e >> 12, colb = (long long)(e & 4095u) * 16, bw = 128 / sim_block;
+          a = pbase + ((row / sim_block) * (stride / bw) + colb / bw) * 128 + (row % sim_block) * bw + colb % bw;
+        }
         if (sim_nt && line_users[(size_t)((a - fbase) >> 7)] == 1) {
           if ((a >> 7) != prev_nt) l2.miss++, prev_nt = a >> 7; else l2.hit++;
           continue;

@@ -74,12 +74,14 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
   o.waves = waves & 0xff;
   o.wide256_pct = (waves >> 8) & 0xfff;   // bits 8..19 of `waves`: PlanOptions::wide256_pct
   o.cost_lines = ((waves >> 20) & 1) != 0;
+  o.scatter = (waves >> 24) & 0xf;        // bits 24..27: PlanOptions::scatter (source strip width in lines)
   waves &= 0xff;
   HostGatherPlan plan;
   if (!plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
   auto wrapi = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
   const int lo = ks == 1 ? 0 : ks / 2 - 1;
-  const size_t cstride = (size_t)tile_chunk_dwords(max_pieces < kMaxPieces ? max_pieces : kMaxPieces);
+  const int mp = max_pieces < kMaxPieces ? max_pieces : kMaxPieces;
+  const size_t cstride = (size_t)tile_chunk_dwords(mp, plan.scatter);
   const size_t wstride = (size_t)tile_words(ks, waves);
   const int per_lane = ks == 8 ? 1 : 4;
   std::vector<unsigned char> cover((size_t)dw * dh, 0);
@@ -103,7 +105,8 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
       }
       memcpy(&lds[(size_t)pos * kStageChunk], src + (size_t)sy * sw + (size_t)cx * kStageChunk, kStageChunk);
     }
-    auto row_base = [&](int r) { return (int)(int16_t)(tc[cstride - 64 + (size_t)(r >> 1)] >> (16 * (r & 1))); };
+    auto row_base = [&](int r) { return (int)(int16_t)(tc[(size_t)mp * kPieceChunks + (size_t)(r >> 1)] >> (16 * (r & 1))); };
+    const uint32_t* origins = tc + (size_t)mp * kPieceChunks + 64;   // scatter tiles: ox | oy << 16 per 4x4 block
     int w = 0, h = 0, lanes = 256, npx = 4;
     switch (t.kind) {
       case kTileStaged32: w = 32; h = 32; break;
@@ -112,12 +115,22 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
       case kTileWide64: w = 64; h = 16; break;
       case kTileWide128: w = 128; h = 16; lanes = 512; break;
       case kTileWide256: w = 256; h = 8; lanes = 512; break;
+      case kTileScatter: w = 128; h = 16; lanes = 512; break;
       default: complain("unknown tile kind", ti, t.ox, t.oy); continue;
     }
     for (int tid = 0; tid < lanes; tid++)
       for (int p = 0; p < npx; p++) {
         int px, py;
-        if (npx == 4) {
+        bool scatter_dead = false;
+        if (t.kind == kTileScatter) {
+          // lanes 4q..4q+3 of band b hold block b*32 + q: column tid & 3, rows 0..3 (the kernel's out_pos())
+          const int q = (tid >> 7) * 32 + ((tid & 127) >> 2);
+          const uint32_t o = origins[q];
+          px = (int)(o & 0xffffu) + (tid & 3);
+          py = (int)(o >> 16) + p;
+          // a block that is not there has dead words and (by convention) origin 0: tell it from a live block at (0, 0)
+          scatter_dead = (words[(size_t)tid * per_lane + p] >> 31) != 0;
+        } else if (npx == 4) {
           px = t.ox + tid % w;
           py = t.oy + (tid / w) * 4 + p;
         } else {
@@ -125,7 +138,8 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
           py = t.oy + (tid >> 4);
         }
         const uint32_t word = words[(size_t)tid * per_lane + p];
-        const bool inside = px < dw && py < dh && py < t.oy + h;
+        if (scatter_dead) continue;
+        const bool inside = t.kind == kTileScatter ? (px < dw && py < dh) : (px < dw && py < dh && py < t.oy + h);
         if (!inside) {
           if (!(word >> 31)) complain("live pixel word outside the plane", ti, px, py);
           continue;

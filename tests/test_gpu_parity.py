@@ -381,6 +381,8 @@ VARIANTS = [
     {"T360_NO_WIDE_LOWPASS": "1"}, {"T360_SMALL_BATCH": "1000"},
     # round 4: 256x8 tiles (kTileWide256) wherever they fit / where they touch fewer lines; extra LDS per workgroup
     {"T360_WIDE256": "1000"}, {"T360_WIDE256": "100", "T360_COST_LINES": "1"}, {"T360_LDS_PAD": "8192"},
+    # scatter tiles (blocks grouped by source position), strips of 1 / 2 / 4 / 8 lines
+    {"T360_SCATTER": "1"}, {"T360_SCATTER": "2"}, {"T360_SCATTER": "4"}, {"T360_SCATTER": "8"},
 ]
 
 

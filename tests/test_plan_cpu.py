@@ -40,7 +40,8 @@ def sim():
     return L
 
 
-@pytest.mark.parametrize("waves,pieces", [(8, 24), (4, 16), (8 | (1000 << 8) | (1 << 20), 24)])  # the third: 256x8 tiles wherever they fit
+@pytest.mark.parametrize("waves,pieces", [(8, 24), (4, 16), (8 | (1000 << 8) | (1 << 20), 24),   # the third: 256x8 tiles wherever they fit
+                                          (8 | (4 << 24), 24), (8 | (2 << 24), 24)])                # scatter tiles, strips of 4 / 2 lines
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gather_through_the_plan_reads_the_right_bytes(name, waves, pieces, sim, oracle_mod):
     O = oracle_mod

@@ -97,6 +97,10 @@ enum : int {
   kTileWide128 = 5,   // 128x16 output px, 4 px per lane on 512 lanes (4 bands): workgroups of 8 waves only
   kTileWide256 = 6,   // 256x8 output px, 4 px per lane on 512 lanes (2 bands): workgroups of 8 waves only; ~490-byte
                       // source row fragments (5 lines for 4 of payload where a 128-wide tile fetches 3 for 2)
+  kTileScatter = 7,   // 128 blocks of 4x4 output px anywhere in the plane, 4 px per lane on 512 lanes (lanes 4q..4q+3 of
+                      // band b = block b*32 + q): the planner groups blocks by where their stencils lie in the SOURCE, so
+                      // the tile's footprint is a compact, line-aligned source rectangle instead of the slanted band an
+                      // output rectangle makes.  Block origins: 128 dwords (ox | oy << 16) behind the tile's row table.
 };
 enum : int {
   kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
@@ -138,7 +142,8 @@ static_assert(sizeof(TileDesc) == 32, "TileDesc must be 32 bytes");
 //                 64 * pieces are meaningful), then the row table: 64 dwords = 128 int16
 // pixel words per tile slot: a uint4 per lane (Lanczos4 plans hold 16x16 tiles only: one word per lane)
 constexpr int tile_words(int ks, int waves) { return ks == 8 ? 256 : 256 * waves; }
-constexpr int tile_chunk_dwords(int max_pieces) { return max_pieces * 64 + 64; }
+constexpr int kScatterBlocks = 128;  // 4x4-px blocks of a scatter tile
+constexpr int tile_chunk_dwords(int max_pieces, bool scatter = false) { return max_pieces * 64 + 64 + (scatter ? kScatterBlocks : 0); }
 constexpr uint32_t kWordDead = 0x80000000u;
 constexpr int kWordRowShift = 11, kWordFracShift = 19;
 constexpr int kBoxMaxCols = 2048 / 16;  // chunk columns of a box

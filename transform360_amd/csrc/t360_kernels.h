@@ -46,6 +46,7 @@ struct TiledPlane {
   int ndirect;              // direct tiles: those of the upper half of the plane first
   int ndirect_top;
   int dst_dword_ok;         // plane base, stride and frame distance are 4-byte aligned: dword stores
+  int scatter;              // this plane's chunk tables carry 128 block origins per tile (scatter plan, t360_plan.h)
 };
 struct TiledArgs {
   const int16_t* wtab;      // OpenCV Q15 table (direct tiles)

@@ -37,6 +37,7 @@ constexpr TileShape kSquare{kTileStaged32, 32, 32, 4, 256};
 constexpr TileShape kSmall{kTileStaged16, 16, 16, 1, 256};
 constexpr TileShape kWide128{kTileWide128, 128, 16, 4, 512};
 constexpr TileShape kWide256{kTileWide256, 256, 8, 4, 512};
+constexpr TileShape kScatter{kTileScatter, 128, 16, 4, 512};  // w, h: the lane grid (128 columns x 4 bands), not a rectangle
 
 inline int floor_div16(int v) { return v >> 4; }  // arithmetic shift: floors negatives too
 inline int wrap(int v, int n) {
@@ -61,6 +62,9 @@ struct Foot {
   int pieces = 0;
   int fetched = 0;        // marked chunks
   int lines = 0;          // distinct 128-byte source lines among them (what the fabric delivers if nothing is shared)
+  std::vector<uint32_t> blocks;  // kTileScatter: origins (ox | oy << 16) of its 4x4-px blocks, block q on lanes 4q..4q+3 of
+                                 // band q / 32
+  uint32_t order_key = 0;        // kTileScatter: position in the execution order (Z-order over source strips and rows)
 };
 
 class Planner {
@@ -72,25 +76,71 @@ class Planner {
     max_pos_ = std::min(opt.max_pieces, kMaxPieces) * kPieceChunks;
   }
 
+  // the output pixel (if any) that lane `tid` holds as its pixel `p`
+  bool pixel_of_lane(const Foot& f, int tid, int p, int* px, int* py) const {
+    const TileShape& s = f.shape;
+    if (s.kind == kTileScatter) {
+      const size_t q = (size_t)(tid >> 7) * 32 + (size_t)((tid & 127) >> 2);
+      if (q >= f.blocks.size()) return false;
+      *px = (int)(f.blocks[q] & 0xffffu) + (tid & 3);
+      *py = (int)(f.blocks[q] >> 16) + p;
+    } else if (s.npx == 4) {
+      *px = f.ox + tid % s.w;
+      *py = f.oy + (tid / s.w) * 4 + p;
+    } else {
+      *px = f.ox + (tid & 15);
+      *py = f.oy + (tid >> 4);
+    }
+    return *px < dw_ && *py < dh_;
+  }
+  // every output pixel of the tile, once
+  template <class Fn>
+  void for_pixels(const Foot& f, Fn&& fn) const {
+    if (f.shape.kind == kTileScatter) {
+      for (uint32_t b : f.blocks)
+        for (int dy = 0; dy < 4; dy++)
+          for (int dx = 0; dx < 4; dx++) fn((int)(b & 0xffffu) + dx, (int)(b >> 16) + dy);
+    } else {
+      const int x1 = std::min(f.ox + f.shape.w, dw_), y1 = std::min(f.oy + f.shape.h, dh_);
+      for (int y = f.oy; y < y1; y++)
+        for (int x = f.ox; x < x1; x++) fn(x, y);
+    }
+  }
+
   void footprint(int ox, int oy, const TileShape& shape, Foot* f) const {
     f->empty = true;
     f->feasible = false;
     f->ox = ox;
     f->oy = oy;
     f->shape = shape;
-    const int x1 = std::min(ox + shape.w, dw_), y1 = std::min(oy + shape.h, dh_);
+    f->blocks.clear();
     if (ox >= dw_ || oy >= dh_) return;
+    measure(f);
+  }
+  // a scatter tile: `blocks` = origins of <= 128 4x4-px blocks (all inside the plane)
+  void footprint_blocks(const std::vector<uint32_t>& blocks, Foot* f) const {
+    f->empty = true;
+    f->feasible = false;
+    f->shape = kScatter;
+    f->blocks = blocks;
+    f->ox = f->oy = 0;
+    if (blocks.empty()) return;
+    f->ox = (int)(blocks[0] & 0xffffu);
+    f->oy = (int)(blocks[0] >> 16);
+    measure(f);
+  }
+
+  // footprint (exact chunk mask), lines and LDS placement of the tile's pixel set
+  void measure(Foot* f) const {
     int minx = 1 << 30, maxx = -(1 << 30), mins = 1 << 30, maxs = -(1 << 30), miny = 1 << 30, maxy = -(1 << 30);
-    for (int y = oy; y < y1; y++) {
-      const LutEntry* row = lut_ + (size_t)y * dw_;
-      for (int x = ox; x < x1; x++) {
-        const int sx = row[x].ix, sy = row[x].iy;
-        const int ss = sx >= (sw_ >> 1) ? sx - sw_ : sx;
-        minx = std::min(minx, sx); maxx = std::max(maxx, sx);
-        mins = std::min(mins, ss); maxs = std::max(maxs, ss);
-        miny = std::min(miny, sy); maxy = std::max(maxy, sy);
-      }
-    }
+    for_pixels(*f, [&](int x, int y) {
+      const LutEntry& e = lut_[(size_t)y * dw_ + x];
+      const int sx = e.ix, sy = e.iy;
+      const int ss = sx >= (sw_ >> 1) ? sx - sw_ : sx;
+      minx = std::min(minx, sx); maxx = std::max(maxx, sx);
+      mins = std::min(mins, ss); maxs = std::max(maxs, ss);
+      miny = std::min(miny, sy); maxy = std::max(maxy, sy);
+    });
     f->empty = false;
     f->seam = (maxs - mins) < (maxx - minx);
     const int xa = (f->seam ? mins : minx) - lo_, xb = (f->seam ? maxs : maxx) + hi_;
@@ -103,22 +153,20 @@ class Planner {
     f->mask.assign((size_t)f->rows * f->ncols, 0);
     f->scanned = false;
     int fetched = 0;
-    for (int y = oy; y < y1; y++) {
-      const LutEntry* row = lut_ + (size_t)y * dw_;
-      for (int x = ox; x < x1; x++) {
-        int sx = row[x].ix;
-        if (f->seam && sx >= (sw_ >> 1)) sx -= sw_;
-        const int ca = floor_div16(sx - lo_) - f->c0, cb = floor_div16(sx + hi_) - f->c0;
-        const int r0 = row[x].iy - lo_ - f->y0;
-        for (int r = r0; r < r0 + opt_.ks; r++) {
-          uint8_t* m = &f->mask[(size_t)r * f->ncols];
-          for (int c = ca; c <= cb; c++) {
-            fetched += m[c] == 0;
-            m[c] = 1;
-          }
+    for_pixels(*f, [&](int x, int y) {
+      const LutEntry& e = lut_[(size_t)y * dw_ + x];
+      int sx = e.ix;
+      if (f->seam && sx >= (sw_ >> 1)) sx -= sw_;
+      const int ca = floor_div16(sx - lo_) - f->c0, cb = floor_div16(sx + hi_) - f->c0;
+      const int r0 = e.iy - lo_ - f->y0;
+      for (int r = r0; r < r0 + opt_.ks; r++) {
+        uint8_t* m = &f->mask[(size_t)r * f->ncols];
+        for (int c = ca; c <= cb; c++) {
+          fetched += m[c] == 0;
+          m[c] = 1;
         }
       }
-    }
+    });
     f->fetched = fetched;
     {
       int lines = 0;
@@ -155,14 +203,7 @@ class Planner {
           for (int l = 0; l < 32; l++) {
             const int tid = g * 32 + l;
             int px, py;
-            if (npx == 4) {
-              px = f->ox + tid % s.w;
-              py = f->oy + (tid / s.w) * 4 + p;
-            } else {
-              px = f->ox + (tid & 15);
-              py = f->oy + (tid >> 4);
-            }
-            if (px >= dw_ || py >= dh_) {
+            if (!pixel_of_lane(*f, tid, p, &px, &py)) {
               tap_row.push_back(-1);
               tap_x.push_back(0);
               continue;
@@ -315,14 +356,7 @@ class Planner {
             for (int l = 0; l < 32; l++) {
               const int tid = g * 32 + l;
               int px, py;
-              if (npx == 4) {
-                px = f.ox + tid % s.w;
-                py = f.oy + (tid / s.w) * 4 + p;
-              } else {
-                px = f.ox + (tid & 15);
-                py = f.oy + (tid >> 4);
-              }
-              if (px >= dw_ || py >= dh_) continue;
+              if (!pixel_of_lane(f, tid, p, &px, &py)) continue;
               const int off = tap_offset(f, lut_[(size_t)py * dw_ + px], k);
               const int a = dual ? (off & ~3) + ((off & 4) ? bbase : 0) : (off & ~3) + 4 * acc;
               for (int j = 0; j < (dual ? 2 : 1); j++) {
@@ -348,7 +382,7 @@ class Planner {
     t.ox = (int16_t)f.ox;
     t.oy = (int16_t)f.oy;
     const TileShape& s = f.shape;
-    const bool partial = f.ox + s.w > dw_ || f.oy + s.h > dh_;
+    const bool partial = s.kind == kTileScatter ? (int)f.blocks.size() < kScatterBlocks : (f.ox + s.w > dw_ || f.oy + s.h > dh_);
     t.flags = (int16_t)((f.seam ? kTileSeamShift : 0) | (partial ? kTilePartial : 0));
     PlanStats& st = out->stats;
     if (!f.feasible) {
@@ -359,11 +393,13 @@ class Planner {
       return;
     }
     t.kind = (int16_t)s.kind;
+    t.pad[0] = (int32_t)f.order_key;
     t.pieces = (int16_t)f.pieces;
     t.rows = (int16_t)f.rows;
     t.fetched = f.fetched;
     // chunk table at a fixed stride: position -> source chunk; holes repeat the previous valid entry
-    const int cstride = tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+    const int mp = std::min(opt_.max_pieces, kMaxPieces);
+    const int cstride = tile_chunk_dwords(mp, scatter_on());
     const size_t base = out->chunks.size();
     out->chunks.resize(base + (size_t)cstride, 0);
     const size_t used = (size_t)f.pieces * kPieceChunks;
@@ -386,15 +422,18 @@ class Planner {
       else
         prev = out->chunks[i];
     }
-    for (size_t i = base + used; i < base + (size_t)cstride - 64; i++) out->chunks[i] = prev;  // never staged, but in bounds
-    // row table: the last 64 dwords
+    for (size_t i = base + used; i < base + (size_t)mp * kPieceChunks; i++) out->chunks[i] = prev;  // never staged, but in bounds
+    // row table: 64 dwords behind the chunk entries
     {
-      const size_t rb = base + (size_t)cstride - 64;
+      const size_t rb = base + (size_t)mp * kPieceChunks;
       for (int r = 0; r < f.rows; r++) {
         const uint32_t v = (uint32_t)(uint16_t)(int16_t)(f.first[(size_t)r] < 0 ? 0 : row_base(f, r));
         out->chunks[rb + (size_t)r / 2] |= v << (16 * (r & 1));
       }
     }
+    // scatter plans: the origins of the tile's 4x4 blocks behind the row table (rectangular tiles of such a plan: unused)
+    if (s.kind == kTileScatter)
+      for (size_t q = 0; q < f.blocks.size(); q++) out->chunks[base + (size_t)mp * kPieceChunks + 64 + q] = f.blocks[q];
     // pixel words at a fixed stride, lane order of the gather; 16x16 tiles of a mixed plan use the first word of a uint4
     const int wstride = tile_words(opt_.ks, opt_.waves);
     const int per_lane = opt_.ks == 8 ? 1 : 4;
@@ -404,14 +443,7 @@ class Planner {
     for (int tid = 0; tid < s.lanes; tid++)
       for (int p = 0; p < s.npx; p++) {
         int px, py;
-        if (s.npx == 4) {
-          px = f.ox + tid % s.w;
-          py = f.oy + (tid / s.w) * 4 + p;
-        } else {
-          px = f.ox + (tid & 15);
-          py = f.oy + (tid >> 4);
-        }
-        if (px >= dw_ || py >= dh_) continue;
+        if (!pixel_of_lane(f, tid, p, &px, &py)) continue;
         const LutEntry& e = lut_[(size_t)py * dw_ + px];
         int sx = e.ix;
         if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
@@ -440,7 +472,7 @@ class Planner {
     st.pieces_hist[f.pieces < 32 ? f.pieces : 32]++;
     if (opt_.model_stats && opt_.ks != 1) st.lds_cycles_model += lds_cycles(f);
     (s.kind == kTileStrip128 ? st.n_strip : s.kind == kTileWide64 ? st.n_wide : s.kind == kTileStaged32 ? st.n_sq
-     : s.kind == kTileWide128 ? st.n_wide128 : s.kind == kTileWide256 ? st.n_wide256 : st.n_16)++;
+     : s.kind == kTileWide128 ? st.n_wide128 : s.kind == kTileWide256 ? st.n_wide256 : s.kind == kTileScatter ? st.n_scatter : st.n_16)++;
   }
 
   // what a tile costs when shapes are compared: the distinct 128-byte lines of its footprint (cost_lines: what the
@@ -568,8 +600,59 @@ class Planner {
     }
     for (Foot& f : pick) emit(f, out, direct);
   }
+  bool scatter_on() const {
+    return opt_.scatter > 0 && opt_.wide256_pct <= 0 && opt_.waves == 8 && (opt_.ks == 2 || opt_.ks == 4) && (dw_ & 3) == 0 && (dh_ & 3) == 0;
+  }
   int region_w() const { return (opt_.waves == 8 && opt_.wide256_pct > 0 && opt_.ks != 8 && opt_.ks != 1) ? 256 : 128; }
 
+
+  // ---- scatter tiles ----------------------------------------------------------------------------------------------
+  // A 128x16 output rectangle on a cube face maps to a SLANTED band of the equirect source: every source row holds a
+  // short fragment of it, and the 128-byte lines under the fragments' ends are fetched by the neighbouring tiles too --
+  // again and again once neighbours drift apart in frame number (2.28x the source plane in distinct lines per tile,
+  // summed over the tiles of BASELINE config 2's luma map).  A scatter tile is cut the other way round:
+  // the plane's 4x4-pixel blocks are sorted by where their stencils lie in the SOURCE (strips of opt_.scatter lines,
+  // top to bottom) and every 128 consecutive blocks form a tile, whose footprint is then a compact source rectangle
+  // (1.79x unshared; with the same drift an LRU model of the L2 reads 1.24x the source instead of 1.45x).
+  struct PoolBlock {
+    uint32_t origin;  // ox | oy << 16
+    int cx, cy;       // centre of the block's stencil box in the source (cx wrapped into the plane)
+  };
+  struct Group {
+    std::vector<uint32_t> blocks;
+    uint32_t key;
+  };
+  // stencil box of the 4x4 block at (bx4, by4) [pixels]; false: too wide / tall to share a tile with its source neighbours
+  bool block_box(int ox, int oy, PoolBlock* b) const {
+    int minx = 1 << 30, maxx = -(1 << 30), mins = 1 << 30, maxs = -(1 << 30), miny = 1 << 30, maxy = -(1 << 30);
+    for (int y = oy; y < oy + 4; y++)
+      for (int x = ox; x < ox + 4; x++) {
+        const LutEntry& e = lut_[(size_t)y * dw_ + x];
+        const int sx = e.ix, ss = sx >= (sw_ >> 1) ? sx - sw_ : sx;
+        minx = std::min(minx, sx); maxx = std::max(maxx, sx);
+        mins = std::min(mins, ss); maxs = std::max(maxs, ss);
+        miny = std::min(miny, (int)e.iy); maxy = std::max(maxy, (int)e.iy);
+      }
+    const bool seam = (maxs - mins) < (maxx - minx);
+    const int xa = seam ? mins : minx, xb = seam ? maxs : maxx;
+    b->origin = (uint32_t)ox | ((uint32_t)oy << 16);
+    b->cx = wrap((xa + xb) / 2, sw_);
+    b->cy = (miny + maxy) / 2;
+    return xb - xa + opt_.ks <= 64 && maxy - miny + opt_.ks <= 40 && miny - lo_ >= 0 && maxy + hi_ < sh_;
+  }
+  // one group of the pool -> one scatter tile, or two halves of it when its footprint does not fit the staging budget
+  bool plan_group(const std::vector<uint32_t>& blocks, uint32_t key, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
+    Foot f;
+    footprint_blocks(blocks, &f);
+    if (f.feasible) {
+      f.order_key = key;
+      emit(f, out, direct);
+      return true;
+    }
+    if (blocks.size() < 2) return false;
+    const std::vector<uint32_t> a(blocks.begin(), blocks.begin() + (long)(blocks.size() / 2)), b(blocks.begin() + (long)(blocks.size() / 2), blocks.end());
+    return plan_group(a, key, out, direct) && plan_group(b, key, out, direct);
+  }
 
   bool run(HostGatherPlan* out) const {
     const int regions_x = (dw_ + region_w() - 1) / region_w(), regions_y = (dh_ + 31) / 32;
@@ -578,11 +661,59 @@ class Planner {
     // a band, so that vertically adjacent tiles -- whose footprints share the stencil halo and the rows a curved
     // footprint adds -- run at the same time on the same XCD.
     std::vector<std::pair<int, int>> regions;
-    for (int ry0 = 0; ry0 < regions_y; ry0 += band)
-      for (int rx = 0; rx < regions_x; rx++)
-        for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) regions.push_back({rx, ry});
-    // regions are independent: plan contiguous slices of the list on a few host threads, splice in order
-    const size_t n = regions.size();
+    std::vector<Group> groups;
+    {
+      std::vector<PoolBlock> pool;
+      for (int ry0 = 0; ry0 < regions_y; ry0 += band)
+        for (int rx = 0; rx < regions_x; rx++)
+          for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) {
+            bool regular = scatter_on();
+            const size_t mark = pool.size();
+            for (int oy = ry * 32; regular && oy < std::min(ry * 32 + 32, dh_); oy += 4)
+              for (int ox = rx * 128; regular && ox < std::min(rx * 128 + 128, dw_); ox += 4) {
+                PoolBlock b;
+                regular = block_box(ox, oy, &b);
+                pool.push_back(b);
+              }
+            if (regular) continue;         // its blocks are in the pool
+            pool.resize(mark);
+            regions.push_back({rx, ry});   // planned as output rectangles (the polar caps, mostly)
+          }
+      if (!pool.empty()) {
+        // strips of opt_.scatter 128-byte lines, top to bottom; a tile = 128 consecutive blocks of a strip
+        const int strip_w = 128 * std::max(1, opt_.scatter);
+        std::stable_sort(pool.begin(), pool.end(), [&](const PoolBlock& a, const PoolBlock& b) {
+          const int sa = a.cx / strip_w, sb = b.cx / strip_w;
+          return sa != sb ? sa < sb : a.cy < b.cy;
+        });
+        auto morton = [](unsigned x, unsigned y) {
+          uint32_t m = 0;
+          for (int b = 0; b < 12; b++) m |= (((x >> b) & 1u) << (2 * b)) | (((y >> b) & 1u) << (2 * b + 1));
+          return m;
+        };
+        size_t i = 0;
+        while (i < pool.size()) {
+          const int strip = pool[i].cx / strip_w;
+          size_t j = i;
+          while (j < pool.size() && j - i < (size_t)kScatterBlocks && pool[j].cx / strip_w == strip) j++;
+          Group g;
+          for (size_t k = i; k < j; k++) g.blocks.push_back(pool[k].origin);
+          // WHICH blocks share a tile is decided in the source; their ORDER inside the tile follows the output raster
+          // (oy, then ox): neighbouring blocks of an output row then sit on neighbouring lane quads, so a wave's stores
+          // are runs of up to 64 contiguous bytes per row again (scattered 4-byte stores made the kernel 4x slower: every
+          // store instruction touched 64 lines) and the 32 lanes of an LDS read are neighbouring columns, as the bank
+          // placement assumes
+          std::sort(g.blocks.begin(), g.blocks.end(), [](uint32_t a, uint32_t b) {
+            return (a >> 16) != (b >> 16) ? (a >> 16) < (b >> 16) : (a & 0xffffu) < (b & 0xffffu);
+          });
+          g.key = morton((unsigned)strip, (unsigned)std::max(0, pool[(i + j) / 2].cy) >> 4);
+          groups.push_back(std::move(g));
+          i = j;
+        }
+      }
+    }
+    // regions and groups are independent: plan contiguous slices of the job list on a few host threads, splice in order
+    const size_t n = regions.size() + groups.size();
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, (n + 7) / 8}));
     std::vector<HostGatherPlan> part(nthreads);
@@ -593,8 +724,12 @@ class Planner {
     auto work = [&](size_t ti) {
       try {
         const size_t lo = n * ti / nthreads, hi = n * (ti + 1) / nthreads;
-        for (size_t i = lo; i < hi && !failed.load(std::memory_order_relaxed); i++)
-          plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
+        for (size_t i = lo; i < hi && !failed.load(std::memory_order_relaxed); i++) {
+          if (i < regions.size())
+            plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
+          else if (!plan_group(groups[i - regions.size()].blocks, groups[i - regions.size()].key, &part[ti], &part_direct[ti]))
+            failed.store(true);
+        }
       } catch (...) {
         failed.store(true);
       }
@@ -627,7 +762,7 @@ class Planner {
       PlanStats& a = out->stats;
       const PlanStats& b = p.stats;
       a.n_strip += b.n_strip; a.n_wide += b.n_wide; a.n_sq += b.n_sq; a.n_16 += b.n_16; a.n_direct += b.n_direct;
-      a.n_wide128 += b.n_wide128; a.n_wide256 += b.n_wide256;
+      a.n_wide128 += b.n_wide128; a.n_wide256 += b.n_wide256; a.n_scatter += b.n_scatter;
       a.fetched_bytes += b.fetched_bytes; a.lds_bytes += b.lds_bytes; a.direct_pixels += b.direct_pixels;
       a.lds_cycles_model += b.lds_cycles_model;
       a.line_bytes += b.line_bytes;
@@ -651,11 +786,14 @@ class Planner {
       std::vector<uint64_t> key(nt);
       for (size_t i = 0; i < nt; i++) {
         const TileDesc& t = tile_at(i);
-        key[i] = ((z ? morton((unsigned)t.ox >> 6, (unsigned)t.oy >> 4) : 0) << 32) | ((uint64_t)(uint16_t)t.oy << 16) | (uint16_t)t.ox;
+        key[i] = t.kind == kTileScatter
+                     ? (uint64_t)(uint32_t)t.pad[0]
+                     : ((uint64_t)1 << 63) | ((z ? morton((unsigned)t.ox >> 6, (unsigned)t.oy >> 4) : 0) << 32) | ((uint64_t)(uint16_t)t.oy << 16) | (uint16_t)t.ox;
       }
       std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
     }
-    const size_t ws = (size_t)tile_words(opt_.ks, opt_.waves), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+    const size_t ws = (size_t)tile_words(opt_.ks, opt_.waves), cs = (size_t)tile_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces), scatter_on());
+    out->scatter = scatter_on();
     out->tiles.assign(nt, TileDesc{});
     out->tlut.assign(nt * ws, 0u);
     out->chunks.assign(nt * cs, 0u);

@@ -21,6 +21,9 @@ struct PlanOptions {
   int wide256_pct = 0;   // > 0 (workgroups of 8 waves): four 256x8 tiles replace a 256x32 region's other tiles when they
                          // cost <= this % of them
   bool cost_lines = false;  // shapes are compared by the distinct 128-byte lines of their footprints, not by chunks
+  int scatter = 0;       // > 0 (workgroups of 8 waves, bilinear / bicubic, plane sides multiples of 4): output regions whose
+                         // 4x4 blocks have compact stencils are cut into SCATTER tiles -- blocks grouped by source position
+                         // in strips of `scatter` 128-byte lines -- instead of output rectangles (kTileScatter)
   int band = 4;          // order 0: region rows walked column by column (execution order, see t360_plan.cpp)
   int order = 2;         // execution order of the tiles: 0 bands of region rows (below), 1 raster, 2 Z-order of 64x16 cells
   int row_pad = 0;       // > 0: up to this many padding chunks behind a staged row (LDS bank spreading)
@@ -33,7 +36,7 @@ struct PlanOptions {
 };
 
 struct PlanStats {
-  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0, n_wide128 = 0, n_wide256 = 0;
+  int n_strip = 0, n_wide = 0, n_sq = 0, n_16 = 0, n_direct = 0, n_wide128 = 0, n_wide256 = 0, n_scatter = 0;
   int64_t fetched_bytes = 0;   // distinct source chunks fetched per frame x 16 (HBM/L2 -> LDS, one copy)
   int64_t lds_bytes = 0;       // LDS positions per frame x 16 (incl. holes), one copy
   int64_t direct_pixels = 0;
@@ -47,6 +50,7 @@ struct HostGatherPlan {
   int ntiles = 0, ndirect = 0, ndirect_top = 0;  // direct tiles: those of the upper half of the plane first
   std::vector<uint32_t> tlut;     // pixel words, lane order (tile_word())
   std::vector<uint32_t> chunks;   // per staged tile 64 * pieces entries: chunk_entry()
+  bool scatter = false;           // the chunk tables carry 128 block origins per tile (tile_chunk_dwords(.., true))
   PlanStats stats;
 };
 

@@ -126,10 +126,11 @@ struct TileFetch {
   uint32_t words[4];  // pixel words of this lane (16x16 tiles: words[0])
   uint32_t chunk[4];  // chunk entries of this lane in pieces wave, wave + WAVES, wave + 2 WAVES, wave + 3 WAVES
   uint32_t rowdw;     // dword `lane` of the row table = row_base of box rows 2*lane and 2*lane + 1
+  uint32_t origin;    // scatter plans: ox | oy << 16 of this lane's 4x4 block (kTileScatter)
 };
 
 template <int KS, int WAVES>
-__device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, int max_pieces) {
+__device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, int max_pieces, bool scatter) {
   TileFetch f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (KS == 8) {
@@ -139,13 +140,15 @@ __device__ __forceinline__ TileFetch fetch_tile(const TiledPlane& pl, int tile, 
     const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)tile * tile_words(KS, WAVES))[tid];
     f.words[0] = v.x; f.words[1] = v.y; f.words[2] = v.z; f.words[3] = v.w;
   }
-  const uint32_t* __restrict__ tc = pl.chunks + (size_t)tile * tile_chunk_dwords(max_pieces);
+  const uint32_t* __restrict__ tc = pl.chunks + (size_t)tile * tile_chunk_dwords(max_pieces, scatter);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int piece = wave + WAVES * j;
     f.chunk[j] = piece < max_pieces ? tc[piece * kPieceChunks + lane] : 0u;
   }
   f.rowdw = tc[max_pieces * kPieceChunks + lane];
+  // (lanes 4q..4q+3 of band b hold block b*32 + q; only 8-wave workgroups run scatter plans)
+  f.origin = scatter && WAVES == 8 ? tc[max_pieces * kPieceChunks + 64 + (tid >> 7) * 32 + ((tid & 127) >> 2)] : 0u;
   return f;
 }
 
@@ -285,6 +288,9 @@ __device__ __forceinline__ uint8_t* uniform_ptr(uint8_t* p) {  // the value IS w
 // is a source line a neighbouring workgroup may still find there (-1 % on the bicubic kernel; the nearest-neighbour
 // kernel, which shares nothing, measured 2 % slower with it; `nt` LOADS make the staging a third slower: they give up
 // exactly the lines the neighbours share.  tools/experiments_r03/gpu_call27.sh, gpu_call28.sh)
+#ifndef T360_STORE_NT
+#define T360_STORE_NT 1
+#endif
 template <bool NT>
 __device__ __forceinline__ void store_dword(uint8_t* base, uint32_t off, uint32_t v) {
   if (NT)
@@ -445,7 +451,8 @@ __device__ __forceinline__ void emit(const PixelSetup<NPX, KS>& s, uint32_t val,
   dbase = T360_UNIFORM(dbase);
   if (NPX == 4) {
     if (dword_store) {
-      store_dword<KS != 1>(dbase, doff, val);
+      // (a scatter tile's missing blocks have dead pixel words on all four lanes of the quad: they store nothing)
+      if (s.live[0]) store_dword<(KS != 1) && T360_STORE_NT>(dbase, doff, val);
     } else {
 #pragma unroll
       for (int p = 0; p < NPX; p++)
@@ -460,11 +467,16 @@ __device__ __forceinline__ void emit(const PixelSetup<NPX, KS>& s, uint32_t val,
 // stores lane (x, band) writes row 4*band + (x & 3), columns (x & ~3)..+3 after the quad transpose; with byte
 // stores it writes its own column x, rows 4*band + 0..3.
 template <int NPX>
-__device__ __forceinline__ uint32_t out_pos(const TiledPlane& pl, const TileDesc& t, bool dword_store) {
+__device__ __forceinline__ uint32_t out_pos(const TiledPlane& pl, const TileDesc& t, bool dword_store, uint32_t origin) {
   const int tid = threadIdx.x;
   int ox, oy;
-  if (NPX == 4) {
-    const int logw = t.kind == kTileWide256 ? 8 : (t.kind == kTileStrip128 || t.kind == kTileWide128) ? 7 : (t.kind == kTileWide64 ? 6 : 5);
+  if (NPX == 4 && t.kind == kTileScatter) {
+    // this lane's 4x4 block sits at `origin`; the lane is its column tid & 3 (byte stores: rows 0..3 of that column) or,
+    // after the quad transpose, its row tid & 3 (one dword)
+    ox = (int)(origin & 0xffffu) + (dword_store ? 0 : (tid & 3));
+    oy = (int)(origin >> 16) + (dword_store ? (tid & 3) : 0);
+  } else if (NPX == 4) {
+    const int logw = t.kind == kTileWide256 ? 8 : (t.kind == kTileStrip128 || t.kind == kTileWide128 || t.kind == kTileScatter) ? 7 : (t.kind == kTileWide64 ? 6 : 5);
     const int x = tid & ((1 << logw) - 1), band = tid >> logw;
     if (dword_store) {
       ox = t.ox + (x & ~3);
@@ -580,7 +592,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   (void)lane;
   const int mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;  // my pieces: wave, wave + WAVES, ... (0..4 of them)
   // does this wave hold pixels?  (a 256-lane tile in a workgroup of 8 waves: waves 4..7 only move bytes)
-  const bool has_px = WAVES == 4 || t.kind == kTileWide128 || t.kind == kTileWide256 || wave < 4;
+  const bool has_px = WAVES == 4 || t.kind == kTileWide128 || t.kind == kTileWide256 || t.kind == kTileScatter || wave < 4;
   // chunk q = lane + 64*piece lives at LDS byte 16*q of each copy; its source (row, 16-byte column) is the plan's
   // (holes repeat a neighbour's chunk): every DMA instruction runs with all 64 lanes.
   int goff[4];  // goff[k] = source offset of my piece 3-k (dma_frame_4's order)
@@ -618,8 +630,8 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
 #endif
   pin_pixels<NPX, KS>(px);
   T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
-  const bool dword_store = NPX == 4 && !(t.flags & kTilePartial) && pl.dst_dword_ok;
-  const uint32_t doff = out_pos<NPX>(pl, t, dword_store);
+  const bool dword_store = NPX == 4 && (!(t.flags & kTilePartial) || t.kind == kTileScatter) && pl.dst_dword_ok;
+  const uint32_t doff = out_pos<NPX>(pl, t, dword_store, tf.origin);
   uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);  // the store uses SGPR base + VGPR offset
   uint32_t pending = 0;
 #ifdef T360_INSTRUMENT
@@ -826,7 +838,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
       }
     }
   }
-  const TileFetch tf = fetch_tile<KS, WAVES>(pl, b, a.max_pieces);  // independent of the descriptor: all in flight together
+  const TileFetch tf = fetch_tile<KS, WAVES>(pl, b, a.max_pieces, pl.scatter != 0);  // independent of the descriptor: all in flight together
   const TileDesc t = pl.tiles[b];
 #ifdef T360_INSTRUMENT
   if (a.trace && threadIdx.x == 0) {

@@ -199,6 +199,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (const char* e = getenv("T360_WIDE64")) plan_wide_pct_ = atoi(e);
   if (const char* e = getenv("T360_STRIPS")) plan_strip_pct_ = atoi(e);
   if (const char* e = getenv("T360_WIDE256")) plan_wide256_pct_ = atoi(e);
+  if (const char* e = getenv("T360_SCATTER")) plan_scatter_ = atoi(e);
   if (const char* e = getenv("T360_COST_LINES")) plan_cost_lines_ = atoi(e);
   if (const char* e = getenv("T360_BAND")) plan_band_ = atoi(e);
   if (const char* e = getenv("T360_ROW_PAD")) plan_row_pad_ = atoi(e);
@@ -1157,6 +1158,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       tp.ndirect_top = gp.ndirect_top;
       tp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 &&
                         (!multi || (j.out_frame_bytes & 3) == 0);
+      tp.scatter = gp.scatter ? 1 : 0;
       if (fused.nplanes == 4 && !flush_fused()) return false;
       fused.plane[fused.nplanes++] = tp;
       fused.total_tiles += tp.ntiles;
@@ -1231,6 +1233,7 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   o.wide_pct = plan_wide_pct_;
   o.strip_pct = plan_strip_pct_;
   o.wide256_pct = small ? 0 : plan_wide256_pct_;
+  o.scatter = small ? 0 : plan_scatter_;
   o.cost_lines = plan_cost_lines_ != 0;
   o.band = plan_band_ > 0 ? plan_band_ : 4;
   o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
@@ -1256,6 +1259,7 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
   g.stats = hp.stats;
   g.waves = waves;
   g.max_pieces = max_pieces;
+  g.scatter = hp.scatter;
   g.valid = true;
   return true;
 }

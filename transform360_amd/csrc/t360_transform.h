@@ -95,6 +95,7 @@ class VideoFrameTransform {
       bool valid = false, tried = false;             // tried: planning was attempted (valid or not plannable)
       int ntiles = 0, ndirect = 0, ndirect_top = 0;  // staged tiles first in `tiles`, the direct tiles behind them
       int waves = 0, max_pieces = 0;                 // what it was planned for
+      bool scatter = false;                          // chunk tables with block origins (scatter plan)
       t360::DeviceBuffer tiles, tlut, chunks;
       t360::PlanStats stats;
     } plan, plan_small;  // plan_small: workgroups of 4 waves, for batches shorter than small_batch_ frames
@@ -153,7 +154,7 @@ class VideoFrameTransform {
   int small_batch_ = 24;       // batches of fewer frames use the 4-wave plan (0: never); measured crossover 24 - 28
   static constexpr int kSmallPlanPieces = 12;
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
-  int plan_wide256_pct_ = 0, plan_cost_lines_ = 0;
+  int plan_wide256_pct_ = 0, plan_cost_lines_ = 0, plan_scatter_ = 0;
   bool use_tiled_ = true;
   char last_kernel_[64] = "";  // gather kernel of the most recent launch (reporting); the buffer lives as long as the handle
   void setLastKernel(const char* name) { snprintf(last_kernel_, sizeof(last_kernel_), "%s", name); }
