@@ -117,7 +117,11 @@ extern "C" long long t360_l2replay(const t360::LutEntry* lut_y, int dwy, int dhy
     for (int i = 0; i < nitems; i++) {
       if (item_xcd[i] != xcd || item_tile[i] < 0 || item_tile[i] >= (int)tiles.size()) continue;
       const int nf = item_f1[i] - item_f0[i];
-      for (int f = 0; f < nf; f++) ev.push_back({item_t0[i] + (item_t1[i] - item_t0[i]) * f / nf, i, item_f0[i] + f});
+      // T360_SIM_ROTATE=period_us: the item starts at the frame a wall clock of that period is on and wraps around
+      // inside its run (every workgroup resident at time t is then near frame t / period: lockstep without waiting)
+      static const double rot_period = getenv("T360_SIM_ROTATE") ? atof(getenv("T360_SIM_ROTATE")) : 0.0;
+      const int phi = rot_period > 0 ? (int)(item_t0[i] / rot_period) % nf : 0;
+      for (int f = 0; f < nf; f++) ev.push_back({item_t0[i] + (item_t1[i] - item_t0[i]) * f / nf, i, item_f0[i] + (phi + f) % nf});
     }
     std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t; });
     L2 l2(l2_bytes, ways);
