@@ -62,6 +62,7 @@ static void sim_options(t360::PlanOptions* o) {
   if (const char* v = getenv("T360_SIM_COST_LINES")) o->cost_lines = atoi(v) != 0;
   if (const char* v = getenv("T360_SIM_WIDE")) o->wide_pct = atoi(v);
   if (const char* v = getenv("T360_SIM_SCATTER")) o->scatter = atoi(v);
+  if (const char* v = getenv("T360_SIM_BAND")) o->band = atoi(v);
 }
 
 static bool build_tiles(const t360::LutEntry* lut_y, int dwy, int dhy, int swy, int shy, const t360::LutEntry* lut_c, int dwc, int dhc,
@@ -121,6 +122,21 @@ extern "C" long long t360_l2replay(const t360::LutEntry* lut_y, int dwy, int dhy
       // inside its run (every workgroup resident at time t is then near frame t / period: lockstep without waiting)
       static const double rot_period = getenv("T360_SIM_ROTATE") ? atof(getenv("T360_SIM_ROTATE")) : 0.0;
       const int phi = rot_period > 0 ? (int)(item_t0[i] / rot_period) % nf : 0;
+      // T360_SIM_FOLLOW=period_us: at EVERY step the item takes the frame the wall clock is on, or the next one after it
+      // that it has not done yet (cyclically): it re-synchronises with everything else that is resident at every step,
+      // and pays for running slower or faster than the clock with frames done alone at the end
+      static const double follow_period = getenv("T360_SIM_FOLLOW") ? atof(getenv("T360_SIM_FOLLOW")) : 0.0;
+      if (follow_period > 0 && nf <= 64) {
+        unsigned long long done = 0;
+        for (int f = 0; f < nf; f++) {
+          const double t = item_t0[i] + (item_t1[i] - item_t0[i]) * f / nf;
+          int fr = (int)((long long)(t / follow_period) % nf);
+          while ((done >> fr) & 1ull) fr = fr + 1 == nf ? 0 : fr + 1;
+          done |= 1ull << fr;
+          ev.push_back({t, i, item_f0[i] + fr});
+        }
+        continue;
+      }
       for (int f = 0; f < nf; f++) ev.push_back({item_t0[i] + (item_t1[i] - item_t0[i]) * f / nf, i, item_f0[i] + (phi + f) % nf});
     }
     std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.t < b.t; });

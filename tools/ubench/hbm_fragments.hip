@@ -13,6 +13,7 @@
 //               neighbours in the row of tiles
 //   overlap     as frames, but the tiles' columns are S / 2 apart: every line is read by TWO tiles, neighbours in id (on
 //               different XCDs: no L2 between them) -- are second reads, microseconds after the first, cheaper?
+//   overlap-xcd as overlap, but the two tiles of a line run on the SAME XCD (ids 8 apart): does its L2 serve the second read?
 //   overlap-far the same tiles, even columns in the first half of the grid and odd columns in the second half: the second
 //               read comes half a launch (~0.7 GB of traffic) after the first
 // Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/hbmfrag hbm_fragments.hip
@@ -44,6 +45,12 @@ __global__ __launch_bounds__(512) void strips(const uint8_t* src, int n_wg, int 
     int c, r, pln;
     if (shuffled == 3) {
       c = u % cols; r = (u / cols) % tile_rows; pln = u / (cols * tile_rows);
+    } else if (shuffled == 5) {
+      // workgroup u runs on XCD u % 8: a row of tiles per XCD at a time, its columns 8 ids apart
+      const unsigned xcd = u & 7, k = u >> 3;
+      const unsigned R = (k / cols) * 8 + xcd;  // row of tiles over all three planes
+      if (R >= 3u * tile_rows) return;
+      c = k % cols; r = R % tile_rows; pln = R / tile_rows;
     } else {
       const unsigned n_even = 3u * tile_rows * strips_per_row;
       if (u < n_even) { c = 2 * (u % strips_per_row); r = (u / strips_per_row) % tile_rows; pln = u / (strips_per_row * tile_rows); }
@@ -85,7 +92,7 @@ int main() {
   (void)hipMalloc(&src, total + (64 << 20)); (void)hipMalloc(&out, 4);
   (void)hipMemset(src, 5, total + (64 << 20));
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-  for (int shuffled = 0; shuffled < 5; shuffled++)
+  for (int shuffled = 0; shuffled < 6; shuffled++)
     for (int S : sizes) {
       const int strips_per_row = kPitch / S;
       int n_wg = 3760 / strips_per_row * strips_per_row;  // whole rows of strips
@@ -98,6 +105,7 @@ int main() {
         if (S > 1280) continue;
         const int cpr = S / 16, rows_per_tile = (512 + cpr - 1) / cpr;
         n_wg = 3 * (2 * strips_per_row - 1) * (1920 / rows_per_tile);
+        if (shuffled == 5) n_wg = (3 * (1920 / rows_per_tile) + 7) / 8 * 8 * (2 * strips_per_row - 1);  // some exit at once; bytes below count the real ones
       }
       float best = 1e9f;
       for (int rep = 0; rep < 3; rep++) {
@@ -114,9 +122,13 @@ int main() {
         float ms; (void)hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
       }
-      const double bytes = (double)n_wg * wg_bytes;
+      double bytes = (double)n_wg * wg_bytes;
+      if (shuffled == 5) {
+        const int cpr = S / 16, rows_per_tile = (512 + cpr - 1) / cpr;
+        bytes = (double)(3 * (2 * strips_per_row - 1) * (1920 / rows_per_tile)) * wg_bytes;
+      }
       printf("fragments of %4d bytes, %-11s: %5d workgroups, %.3f ms for %.0f MB -> %.2f TB/s (%.1f GB/s per CU)\n", S,
-             shuffled == 4 ? "overlap-far" : shuffled == 3 ? "overlap" : shuffled == 2 ? "frames" : shuffled ? "shuffled" : "row-major", n_wg, best, bytes / 1e6, bytes / best / 1e9, bytes / best / 1e6 / 256);
+             shuffled == 5 ? "overlap-xcd" : shuffled == 4 ? "overlap-far" : shuffled == 3 ? "overlap" : shuffled == 2 ? "frames" : shuffled ? "shuffled" : "row-major", n_wg, best, bytes / 1e6, bytes / best / 1e9, bytes / best / 1e6 / 256);
     }
   return 0;
 }

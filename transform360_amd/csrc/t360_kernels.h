@@ -66,6 +66,7 @@ struct TiledArgs {
   int waves;
 #ifdef T360_INSTRUMENT
   int lds_pad;              // instrumented build only: extra dynamic LDS per workgroup (occupancy experiments)
+  int k_lo, k_hi;           // instrumented build only (INCOMPLETE OUTPUT): only work items k_lo <= k < k_hi of every XCD run (k_hi 0 = all)
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
                             // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B,
                             // bit6 every frame reads frame 0's source (L2 hits), bit7 no frame barrier, bit8 no output stores

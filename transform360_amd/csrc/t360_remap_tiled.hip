@@ -803,6 +803,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     // whose footprints overlap by the stencil halo -- share an L2
     id -= a.direct_blocks;
     const int xcd = id & 7, k = id >> 3;
+#ifdef T360_INSTRUMENT
+    if (a.k_hi > 0 && (k < a.k_lo || k >= a.k_hi)) return;  // generation experiments: a slice of every XCD's list only
+#endif
     const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
     const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
     // The last tiles of every XCD's range walk the batch in shorter runs (tail_frames instead of frames_per_block):

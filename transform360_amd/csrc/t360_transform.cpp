@@ -1059,6 +1059,8 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
 #ifdef T360_INSTRUMENT
     fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
     fused.lds_pad = getenv("T360_LDS_PAD") ? atoi(getenv("T360_LDS_PAD")) : 0;
+    fused.k_lo = getenv("T360_K_LO") ? atoi(getenv("T360_K_LO")) : 0;
+    fused.k_hi = getenv("T360_K_HI") ? atoi(getenv("T360_K_HI")) : 0;
 #endif
   };
   auto flush_fused = [&]() -> bool {
