@@ -62,7 +62,7 @@ items = np.array(items, dtype=np.float64)
 print("items %d, span %.1f us; xcc ids seen %s" % (len(items), items[:, 5].max(), sorted(set(items[:, 3].astype(int)))))
 n = len(items)
 arr = lambda col, ct: (ct * n)(*[ct(v).value if ct is C.c_double else int(v) for v in items[:, col]])
-for l2kb in (4096, 2048, 1024):
+for l2kb in (16384, 8192, 4096, 2048, 1024):
     r = L.t360_l2replay(C.c_void_p(ly.ctypes.data), dwy, dhy, swy, shy, C.c_void_p(lc.ctypes.data), dwc, dhc, swc, shc, ks, 24, 8, 2,
                         l2kb << 10, 16, n, arr(0, C.c_int), arr(1, C.c_int), arr(2, C.c_int), arr(3, C.c_int),
                         arr(4, C.c_double), arr(5, C.c_double), st)
