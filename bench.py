@@ -82,6 +82,57 @@ def workload(config):
     raise SystemExit("unknown --config %r" % config)
 
 
+def host_cpu_allowance():
+    """What this process may actually use of the host: the scheduler affinity mask and the cgroup CPU quota (v2 cpu.max,
+    v1 cfs_quota_us / cfs_period_us, of this process's own cgroup where /proc/self/cgroup names one).  os.cpu_count() is the
+    node's logical cores, which a leased box usually does not get."""
+    out = {"logical_cores_of_the_node": os.cpu_count() or 1}
+    try:
+        out["sched_affinity_cores"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        out["sched_affinity_cores"] = None
+    quota = None
+    paths = ["/sys/fs/cgroup"]
+    try:
+        with open("/proc/self/cgroup") as f:
+            for line in f:
+                parts = line.strip().split(":", 2)
+                if len(parts) == 3 and parts[2] not in ("", "/"):
+                    if parts[1] == "":
+                        paths.insert(0, "/sys/fs/cgroup" + parts[2])
+                    elif "cpu" in parts[1].split(","):
+                        paths.insert(0, "/sys/fs/cgroup/cpu" + parts[2])
+    except OSError:
+        pass
+    for base in paths + ["/sys/fs/cgroup/cpu"]:
+        try:
+            with open(os.path.join(base, "cpu.max")) as f:
+                q, per = f.read().split()[:2]
+                out["cgroup_cpu_max"] = "%s %s" % (q, per)
+                if q != "max":
+                    quota = float(q) / float(per)
+                break
+        except (OSError, ValueError):
+            pass
+        try:
+            with open(os.path.join(base, "cpu.cfs_quota_us")) as f:
+                q = int(f.read())
+            with open(os.path.join(base, "cpu.cfs_period_us")) as f:
+                per = int(f.read())
+            out["cgroup_cfs_quota_us/period_us"] = "%d/%d" % (q, per)
+            if q > 0 and per > 0:
+                quota = q / per
+            break
+        except (OSError, ValueError):
+            pass
+    out["cgroup_cpu_quota_cores"] = round(quota, 2) if quota is not None else None
+    usable = out["sched_affinity_cores"] or out["logical_cores_of_the_node"]
+    if quota is not None:
+        usable = min(usable, max(1, int(quota + 0.5)))
+    out["usable_cores"] = usable
+    return out
+
+
 def cpu_baseline(wl, lin, lout, budget_s):
     """The oracle on the host cores: remap in row stripes over T threads, low-pass one task per
     segment (the reference's structure), planes sequentially (vf_transform360.c:368-397)."""
@@ -90,7 +141,8 @@ def cpu_baseline(wl, lin, lout, budget_s):
     from oracle import t360_oracle as O
     from transform360_amd.abi import filter_defaults
     from transform360_amd.handler import frame_seed, noise_bytes
-    T = os.cpu_count() or 1
+    allowance = host_cpu_allowance()
+    T = allowance["usable_cores"]
     ctx = filter_defaults(**wl["ov"])
     t0 = time.perf_counter()
     o = O.Oracle(ctx, threads=T)
@@ -170,10 +222,13 @@ def cpu_baseline(wl, lin, lout, budget_s):
         "value": round(fps * mpix, 3), "unit": "Mpix/s", "cores": best_t, "kind": "port",
         "frame_parallel_streams": frame_parallel,
         "sample": "%d frames of the same workload in %.1f s on %d threads, the best of a thread sweep %s on a host "
-                  "with %d logical cores (oracle = restatement of the reference's OpenCV path, not linked OpenCV); "
+                  "that lets this process use %d cores (affinity mask %s, cgroup quota %s cores, node %d logical cores; oracle = "
+                  "restatement of the reference's OpenCV path, not linked OpenCV); "
                   "map init %.2f s" % (n, el, best_t,
-                                        {th: round(r[0] * mpix, 1) for th, r in sorted(results.items())}, T, init_s),
-        "cpu_model": model, "host_cores": T, "fps": round(fps, 3), "value_1thread": round(fps1 * mpix, 3),
+                                        {th: round(r[0] * mpix, 1) for th, r in sorted(results.items())}, T,
+                                        allowance["sched_affinity_cores"], allowance["cgroup_cpu_quota_cores"],
+                                        allowance["logical_cores_of_the_node"], init_s),
+        "cpu_model": model, "host_cores": T, "host_cpu_allowance": allowance, "fps": round(fps, 3), "value_1thread": round(fps1 * mpix, 3),
     }
 
 
@@ -310,6 +365,20 @@ class HipPath:
         if events is not None:
             events[1].record(self.stream)
 
+    def set_pipeline(self, depth):
+        """T360_transformFramesPipelined on the ONE handle: consecutive (independent) steps go round-robin over `depth`
+        internal streams of the library; output buffers rotate with the lanes (buffer 0 is d_out)"""
+        assert self.t.setPipelineDepth(depth)
+        self.pipe_depth = depth
+        while len(getattr(self, "pipe_outs", [self.d_out])) < depth:
+            self.pipe_outs = getattr(self, "pipe_outs", [self.d_out]) + [self.torch.zeros_like(self.d_out)]
+        self.pipe_outs = getattr(self, "pipe_outs", [self.d_out])
+
+    def step_pipelined(self, n_frames, inp=None):
+        k = getattr(self, "k", 0)
+        assert self.t.transformFramesPipelined(self.d_in if inp is None else inp, self.lin.frame_bytes,
+                                               self.pipe_outs[k % self.pipe_depth], self.lout.frame_bytes, n_frames, self.descs)
+
     def new_events(self, n):
         return [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(n)]
 
@@ -321,6 +390,7 @@ class HipPath:
         return pair[0].elapsed_time(pair[1])
 
     def sync(self):
+        # (a device-wide wait: it covers the library's internal pipeline streams as well)
         self.torch.cuda.synchronize()
 
     def new_output(self):
@@ -486,7 +556,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             dist.barrier()
             path.sync()
 
-    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False, before_step=None, alternate=False):
+    busy = {"s": 0.0}   # wall-clock seconds this rank kept the GPU busy with transform steps (timed or not)
+
+    def timed_run(n_frames, steps, with_events, after_step=None, rotate=False, before_step=None, alternate=False, pipelined=False):
         """REPEATS x (exactly `steps` steps between barriers); per repeat (elapsed max over ranks, [launch ms]).
         rotate: step k reads the k-th group of n_frames input frames of this rank's F (a short step must not find its
         input in the 256 MB Infinity Cache just because every step reads the same few frames)."""
@@ -508,7 +580,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 if before_step is not None:
                     before_step(k)
                 inp = ring[(k % groups) * n_frames * lin.frame_bytes:] if ring is not None else None
-                if alternate and (k & 1):
+                if pipelined:
+                    path.step_pipelined(n_frames, inp=inp)
+                elif alternate and (k & 1):
                     path.step2(n_frames, inp=inp)
                 elif inp is not None:
                     path.step(n_frames, inp=inp)
@@ -522,6 +596,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 after_step(None)  # drain
             path.sync()
             elapsed = time.perf_counter() - t0
+            busy["s"] += elapsed
             if dist is not None:
                 dist.barrier()
                 el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -559,6 +634,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         warm_steps(F, 8, clock_warmup_steps)
         path.sync()
         clock_warmup_steps += 8
+    busy["s"] += time.perf_counter() - t_w
     warm_steps(F, args.warmup)
     runs = timed_run(F, args.steps, True, rotate=rotate)
     if getattr(path, "groups", 1) > 1:
@@ -586,17 +662,20 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             strong["input"] = "every step reads other frames of the rank's %d-frame ring (HBM)" % (getattr(path, "groups", 1) * F)
             strong["ms_per_step_same_input_every_step"] = round(c_el / args.steps * 1e3, 4)
         if path.name == "hip" and not args.no_two_streams:
-            # The same steps alternating between TWO handles on two streams (two output buffers): a frame stream's
-            # consecutive batches are independent, so step k+1's workgroups start while step k's last ones drain
-            # (VERDICT round 3, item 2).  A second figure, next to the one-stream one above.
-            path.second_handle()
-            for k in range(4):
-                (path.step2 if k & 1 else path.step)(f5)
-            pruns = timed_run(f5, args.steps, False, rotate=rotate, alternate=True)
+            # The same steps through T360_transformFramesPipelined (ONE handle, the library's internal streams): a frame
+            # stream's consecutive batches are independent, so step k+1's workgroups start while step k's last ones drain
+            # (the overlap is a product feature now, not two handles in the benchmark).
+            path.set_pipeline(args.pipeline_depth)
+            for k in range(2 * args.pipeline_depth):
+                path.k = k
+                path.step_pipelined(f5)
+            path.sync()
+            pruns = timed_run(f5, args.steps, False, rotate=rotate, pipelined=True)
             p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
-            strong["two_streams"] = {"what": "steps alternate between two handles on two HIP streams (independent batches, two output buffers)",
-                                     "ms_per_step": round(p_el / args.steps * 1e3, 4),
-                                     "value": round(min(64, f5 * world) * args.steps / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s"}
+            strong["pipelined"] = {"what": "the same steps through T360_transformFramesPipelined: one handle, %d internal streams, "
+                                           "independent batches, %d output buffers" % (args.pipeline_depth, args.pipeline_depth),
+                                   "ms_per_step": round(p_el / args.steps * 1e3, 4),
+                                   "value": round(min(64, f5 * world) * args.steps / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s"}
         if world == 1 and F >= 64 and path.name == "hip":
             # what ONE GPU of an 8-GPU node runs for configs[4]: 8 of the 64 frames per step.  Timed here on one GPU (input
             # rotating through the ring, so from HBM): the projected strong-scaling factor is t(64 frames) / t(8 frames).
@@ -614,26 +693,47 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 "what": "one GPU's share at 8 GPUs (8 frames per step) timed on this GPU; speedup = this line's 64-frame step time / "
                         "the 8-frame step time (no inter-GPU traffic on the path: frames are sharded, SURVEY 8e)"}
             if not args.no_two_streams:
-                for k in range(4):
-                    (path.step2 if k & 1 else path.step)(8)
-                e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, alternate=True))[REPEATS // 2]
-                strong["projected_8_gpus"]["two_streams_ms_per_step"] = round(e8p / args.steps * 1e3, 4)
-                strong["projected_8_gpus"]["two_streams_speedup_over_1_gpu"] = round(s_el / e8p, 2)
+                for k in range(2 * args.pipeline_depth):
+                    path.k = k
+                    path.step_pipelined(8)
+                path.sync()
+                e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, pipelined=True))[REPEATS // 2]
+                strong["projected_8_gpus"]["pipelined_ms_per_step"] = round(e8p / args.steps * 1e3, 4)
+                strong["projected_8_gpus"]["pipelined_speedup_over_1_gpu"] = round(s_el / e8p, 2)
+                strong["projected_8_gpus"]["pipelined_what"] = ("8-frame steps through T360_transformFramesPipelined (depth %d) against "
+                                                                "this line's one-stream 64-frame step" % args.pipeline_depth)
         if f5 * world != 64:
             strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
 
     pipelined = None
-    if args.config == 2 and path.name == "hip" and world == 1 and not args.no_two_streams:
-        path.second_handle()
-        for k in range(4):
-            (path.step2 if k & 1 else path.step)(F)
-        pruns = timed_run(F, args.steps, False, rotate=rotate, alternate=True)
+    if path.name == "hip" and not args.no_two_streams:
+        path.set_pipeline(args.pipeline_depth)
+        for k in range(2 * args.pipeline_depth):
+            path.k = k
+            path.step_pipelined(F)
+        path.sync()
+        pruns = timed_run(F, args.steps, False, rotate=rotate, pipelined=True)
         p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
-        pipelined = {"what": "the headline steps alternating between two handles on two HIP streams (independent batches, two "
-                             "output buffers): step k+1 starts while step k drains; NOT the `value` above, whose launches are "
-                             "back to back on one stream",
+        pipelined = {"what": "the headline steps through T360_transformFramesPipelined (one handle, %d internal streams, independent "
+                             "batches, %d output buffers): step k+1 starts while step k drains; NOT the `value` above, whose "
+                             "launches are back to back on one stream" % (args.pipeline_depth, args.pipeline_depth),
                      "ms_per_step": round(p_el / args.steps * 1e3, 4),
-                     "value": round(args.steps * F * world / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s"}
+                     "value": round(args.steps * F * world / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                     "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in pruns]}
+        path.step(F)  # d_out holds group 0's full-batch result again
+        path.sync()
+
+    two_handles = None
+    if args.two_handles and path.name == "hip" and world == 1:
+        # development comparison: the round-4 way of getting the overlap (two handles, two streams, no ordering events)
+        path.second_handle()
+        two_handles = {}
+        for nfr in sorted({8, F}):
+            for k in range(4):
+                (path.step2 if k & 1 else path.step)(nfr)
+            path.sync()
+            th = sorted(r[0] for r in timed_run(nfr, args.steps, False, rotate=rotate, alternate=True))[REPEATS // 2]
+            two_handles["%d_frames_ms_per_step" % nfr] = round(th / args.steps * 1e3, 4)
 
     # the same steps with every step's output frames gathered to rank 0 (RCCL gather over xGMI; a
     # device copy when there is one rank), overlapped with the next step: outputs alternate between two buffers and a
@@ -785,7 +885,11 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         res = {
             "metric": ("Mpix/s remapped (4K equirect→512-edge cubemap, bicubic)" if args.config == 2
                        else "Mpix/s remapped (%s)" % wl["name"]) if path.name == "hip" else "STUB (no transform ran)",
+            # the two scaling figures side by side at the head of the line: `value` is WEAK
+            # scaling (F frames per GPU and step), `strong_cfg5_value` is BASELINE configs[4] as written (64 frames in
+            # total per step, ceil(64 / N) per GPU); details of the latter under "strong_cfg5"
             "value": round(fps * out_mpix, 1), "unit": "Mpix/s",
+            "strong_cfg5_value": strong["value"] if strong is not None else None,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -799,6 +903,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             "input_ring": {"groups_of_F_frames": getattr(path, "groups", 1), "bytes": getattr(path, "groups", 1) * F * lin.frame_bytes,
                            "why": "timed steps rotate through this much distinct input when one step's input would fit the 256 MB Infinity Cache"},
             "frames_timed_per_gpu": REPEATS * args.steps * F,
+            # context for the timed region: `ms_per_step` x steps is a few milliseconds; over the
+            # whole run this rank kept the GPU busy with transform steps (clock ramp, warm-up, every timed leg) for
+            "gpu_busy_s_all_legs": round(busy["s"], 3),
             "frac_of_hbm_roofline_whole_job": round(alg_frame * fps / (HBM_PEAK_BPS * world), 4),
             "roofline": {
                 "bound": "hbm",
@@ -818,7 +925,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         if strong is not None:
             res["strong_cfg5"] = strong
         if pipelined is not None:
-            res["two_streams"] = pipelined
+            res["pipelined"] = pipelined
+        if two_handles is not None:
+            res["two_handles"] = two_handles
         if gathered is not None:
             res["gather_outputs"] = gathered
         if scattered is not None:
@@ -841,9 +950,11 @@ def main():
                     help="also time the steps with every step's output frames gathered to rank 0, overlapped with the next step")
     ap.add_argument("--scatter-inputs", action="store_true",
                     help="also time the steps with the inputs scattered from rank 0 and the outputs gathered to it, overlapped")
-    ap.add_argument("--no-two-streams", action="store_true",
-                    help="skip the legs that alternate steps between two handles on two streams (kernel traces: overlapped "
+    ap.add_argument("--no-two-streams", "--no-pipelined", dest="no_two_streams", action="store_true",
+                    help="skip the legs that issue steps through T360_transformFramesPipelined (kernel traces: overlapped "
                          "launches of the hot kernel would enter its average duration)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="internal streams of the pipelined legs (1..4)")
+    ap.add_argument("--two-handles", action="store_true", help="also time steps alternating between two handles on two streams (development)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
     args = ap.parse_args()

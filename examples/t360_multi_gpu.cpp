@@ -4,7 +4,12 @@
 // side stream, overlapped with the next step through two output buffers).  bench.py does the same with one process per
 // GPU under torch.distributed; this file is what an integrator who links -lTransform360 -lrccl would write.
 //
-//   make -C examples && examples/t360_multi_gpu [--devices N] [--frames F] [--steps K] [--gather]
+//   make -C examples && examples/t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K]
+//                                                  [--pipelined D] [--gather]
+//
+// --workers W > devices rehearses the W-GPU process on fewer GPUs (workers share devices; no gather then);
+// --total-frames 64 is BASELINE configs[4] as written (64 frames sharded over the workers: strong scaling);
+// --pipelined D issues the steps through T360_transformFramesPipelined on D internal streams per handle.
 //
 // Workload: BASELINE config 2 (3840x1920 yuv420p -> 1536x1024 CUBEMAP_32, bicubic, low-pass off), F frames per device
 // and step, resident in device memory.  Prints one line per device and the aggregate rate; the checksum of device d's
@@ -20,6 +25,7 @@
 #include <vector>
 
 #include "Transform360/t360_device.h"
+#include "t360_shard_plan.h"
 
 namespace {
 
@@ -86,110 +92,152 @@ FrameTransformContext config2() {
 }  // namespace
 
 int main(int argc, char** argv) {
-  int ndev = T360_deviceCount(), F = 64, steps = 20;
+  using namespace t360_example;
+  const int visible = T360_deviceCount();
+  int ndev = visible, workers = 0, F = 64, steps = 20, total_frames = 0, depth = 0;
   bool gather = false;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--workers") && i + 1 < argc) workers = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--frames") && i + 1 < argc) F = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--total-frames") && i + 1 < argc) total_frames = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--pipelined") && i + 1 < argc) depth = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--gather")) gather = true;
+    else {
+      fprintf(stderr, "usage: t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K] [--pipelined D] [--gather]\n");
+      return 2;
+    }
   }
-  if (ndev < 1 || ndev > T360_deviceCount()) {
-    fprintf(stderr, "no such number of devices (%d visible)\n", T360_deviceCount());
+  if (ndev < 1 || ndev > visible) {
+    fprintf(stderr, "no such number of devices (%d visible)\n", visible);
     return 1;
+  }
+  // A worker = one host thread + handle + stream; worker w runs on device w % ndev.  Normally one worker per device; MORE
+  // workers than devices is the rehearsal of the N-GPU process on a box with fewer GPUs (every code path of the N-worker
+  // run except the RCCL gather, which needs distinct devices).
+  if (workers <= 0) workers = ndev;
+  std::vector<int> device_of((size_t)workers);
+  for (int w = 0; w < workers; w++) device_of[(size_t)w] = w % ndev;
+  if (gather && !gather_possible(device_of)) {
+    printf("note: --gather needs one device per worker (RCCL refuses duplicate devices in a communicator): compute only\n");
+    gather = false;
+  }
+  // weak scaling (default): F frames per worker and step; --total-frames T (BASELINE configs[4]: T = 64): the T frames of
+  // a step are sharded over the workers in contiguous blocks, worker w owns [lo_w, hi_w)
+  std::vector<int> lo((size_t)workers), hi((size_t)workers);
+  for (int w = 0; w < workers; w++) {
+    if (total_frames > 0) shard_range(total_frames, w, workers, &lo[(size_t)w], &hi[(size_t)w]);
+    else lo[(size_t)w] = w * F, hi[(size_t)w] = (w + 1) * F;
   }
   const FrameLayout lin(3840, 1920), lout(1536, 1024);
   T360PlaneDesc planes[3];
   for (int k = 0; k < 3; k++)
     planes[k] = T360PlaneDesc{lin.off[k], lout.off[k], lin.stride[k], lout.stride[k], lin.w[k], lin.h[k], lout.w[k], lout.h[k], k ? 1 : 0};
+  std::vector<int64_t> out_bytes_of((size_t)workers);
+  int64_t sink_bytes = 0;
+  for (int w = 0; w < workers; w++) sink_bytes += out_bytes_of[(size_t)w] = (int64_t)(hi[(size_t)w] - lo[(size_t)w]) * lout.frame_bytes;
 
-  std::vector<ncclComm_t> comms((size_t)ndev);
-  gather = gather && ndev > 1;
-  if (gather) {
-    std::vector<int> devs((size_t)ndev);
-    for (int d = 0; d < ndev; d++) devs[(size_t)d] = d;
-    CHECK_NCCL(ncclCommInitAll(comms.data(), ndev, devs.data()));
-  }
-  std::vector<double> ms((size_t)ndev);
-  std::vector<unsigned long long> sums((size_t)ndev);
-  auto worker = [&](int d) {
-    CHECK_HIP(hipSetDevice(d));  // a handle lives on the device that is current when it is created
+  std::vector<ncclComm_t> comms((size_t)workers);
+  if (gather) CHECK_NCCL(ncclCommInitAll(comms.data(), workers, device_of.data()));
+  std::vector<double> ms((size_t)workers);
+  std::vector<unsigned long long> sums((size_t)workers);
+  auto worker = [&](int w) {
+    const int nf = hi[(size_t)w] - lo[(size_t)w];
+    CHECK_HIP(hipSetDevice(device_of[(size_t)w]));  // a handle lives on the device that is current when it is created
     hipStream_t stream, side;
     CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     FrameTransformContext ctx = config2();
     VideoFrameTransform* t = VideoFrameTransform_new(&ctx);
     if (!t || !VideoFrameTransform_generateMapForPlane(t, lin.w[0], lin.h[0], lout.w[0], lout.h[0], 0) ||
-        !VideoFrameTransform_generateMapForPlane(t, lin.w[1], lin.h[1], lout.w[1], lout.h[1], 1) || !T360_setStream(t, stream)) {
-      fprintf(stderr, "device %d: initialisation failed\n", d);
+        !VideoFrameTransform_generateMapForPlane(t, lin.w[1], lin.h[1], lout.w[1], lout.h[1], 1) || !T360_setStream(t, stream) ||
+        (depth > 0 && !T360_setPipelineDepth(t, depth))) {
+      fprintf(stderr, "worker %d: initialisation failed\n", w);
       exit(1);
     }
-    uint8_t *d_in, *d_out[2], *sink = nullptr;
-    CHECK_HIP(hipMalloc(&d_in, (size_t)F * lin.frame_bytes));
-    for (int b = 0; b < 2; b++) CHECK_HIP(hipMalloc(&d_out[b], (size_t)F * lout.frame_bytes));
-    if (gather && d == 0) CHECK_HIP(hipMalloc(&sink, (size_t)ndev * F * lout.frame_bytes));
-    for (int j = 0; j < F; j++)  // frame j of device d = frame d*F + j of the synthetic stream (bench.py's seeds)
-      T360_fillNoise(d_in + (size_t)j * lin.frame_bytes, lin.frame_bytes, (0x360ull ^ ((unsigned long long)(d * F + j) << 40)) & 0xffffffffffffffffull, stream);
+    const int nbuf = depth > 2 ? depth : 2;  // an output buffer is reused every `depth` pipelined calls
+    uint8_t *d_in, *sink = nullptr;
+    std::vector<uint8_t*> d_out((size_t)nbuf);
+    CHECK_HIP(hipMalloc(&d_in, (size_t)(nf > 0 ? nf : 1) * lin.frame_bytes));
+    for (int b = 0; b < nbuf; b++) CHECK_HIP(hipMalloc(&d_out[(size_t)b], (size_t)(nf > 0 ? nf : 1) * lout.frame_bytes));
+    if (gather && w == 0) CHECK_HIP(hipMalloc(&sink, (size_t)sink_bytes));
+    for (int j = 0; j < nf; j++)  // frame j of worker w = frame lo_w + j of the synthetic stream (bench.py's seeds)
+      T360_fillNoise(d_in + (size_t)j * lin.frame_bytes, lin.frame_bytes, (0x360ull ^ ((unsigned long long)(lo[(size_t)w] + j) << 40)) & 0xffffffffffffffffull, stream);
     hipEvent_t done[2], sent[2];
     for (int b = 0; b < 2; b++) {
       CHECK_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
       CHECK_HIP(hipEventCreateWithFlags(&sent[b], hipEventDisableTiming));
     }
+    const std::vector<P2POp> ops = gather ? gather_ops(w, out_bytes_of) : std::vector<P2POp>();
+    auto transform = [&](uint8_t* out) {
+      if (nf == 0) return;
+      const int ok = depth > 0 ? T360_transformFramesPipelined(t, d_in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3)
+                               : T360_transformFrames(t, d_in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3);
+      if (!ok) exit(1);
+    };
     auto step = [&](int k) {
-      const int b = k & 1;
-      if (gather && k >= 2) CHECK_HIP(hipStreamWaitEvent(stream, sent[b], 0));  // the gather that read this buffer is over
-      if (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[b], lout.frame_bytes, F, planes, 3)) exit(1);
-      if (gather) {
-        CHECK_HIP(hipEventRecord(done[b], stream));
-        CHECK_HIP(hipStreamWaitEvent(side, done[b], 0));
-        CHECK_NCCL(ncclGroupStart());
-        if (d != 0) CHECK_NCCL(ncclSend(d_out[b], (size_t)F * lout.frame_bytes, ncclUint8, 0, comms[(size_t)d], side));
-        if (d == 0)
-          for (int r = 1; r < ndev; r++)
-            CHECK_NCCL(ncclRecv(sink + (size_t)r * F * lout.frame_bytes, (size_t)F * lout.frame_bytes, ncclUint8, r, comms[0], side));
-        CHECK_NCCL(ncclGroupEnd());
-        CHECK_HIP(hipEventRecord(sent[b], side));
+      if (!gather) {
+        transform(d_out[(size_t)(k % nbuf)]);
+        return;
       }
+      const int b = buffer_of_step(k);
+      if (step_waits_for_gather(k)) CHECK_HIP(hipStreamWaitEvent(stream, sent[b], 0));  // the gather that read this buffer is over
+      transform(d_out[(size_t)b]);
+      if (depth > 0 && !T360_pipelineJoin(t)) exit(1);  // the send below is ordered on `stream`
+      CHECK_HIP(hipEventRecord(done[b], stream));
+      CHECK_HIP(hipStreamWaitEvent(side, done[b], 0));
+      CHECK_NCCL(ncclGroupStart());
+      for (const P2POp& op : ops) {
+        if (op.send) CHECK_NCCL(ncclSend(d_out[(size_t)b], (size_t)op.bytes, ncclUint8, op.peer, comms[(size_t)w], side));
+        else CHECK_NCCL(ncclRecv(sink + op.offset, (size_t)op.bytes, ncclUint8, op.peer, comms[(size_t)w], side));
+      }
+      CHECK_NCCL(ncclGroupEnd());
+      CHECK_HIP(hipEventRecord(sent[b], side));
     };
     // warm-up in two parts.  (1) The clock ramp -- the first step plans the gather, and the clocks need a few hundred
     // milliseconds of load to come up -- runs the transform ALONE: its length is this thread's own wall clock, and a
-    // loop of that kind must not post collectives (devices would post different numbers of sends and receives and
-    // the side streams would never drain).  (2) A FIXED number of full steps, the same on every device, primes the
+    // loop of that kind must not post collectives (workers would post different numbers of sends and receives and
+    // the side streams would never drain).  (2) A FIXED number of full steps, the same on every worker, primes the
     // gather path and its double buffering.
     for (const auto w0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - w0 < std::chrono::milliseconds(400);) {
-      for (int k = 0; k < 8; k++)
-        if (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[k & 1], lout.frame_bytes, F, planes, 3)) exit(1);
-      CHECK_HIP(hipStreamSynchronize(stream));
+      for (int k = 0; k < 8; k++) transform(d_out[(size_t)(k % nbuf)]);
+      if (!T360_synchronize(t)) exit(1);
     }
     constexpr int kWarmSteps = 4;  // even: the timed loop starts on buffer 0 with both `sent` events recorded
     for (int k = 0; k < kWarmSteps; k++) step(k);
-    CHECK_HIP(hipStreamSynchronize(stream));
+    if (!T360_synchronize(t)) exit(1);
     CHECK_HIP(hipStreamSynchronize(side));
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; k++) step(k);
-    CHECK_HIP(hipStreamSynchronize(stream));
+    if (!T360_synchronize(t)) exit(1);  // the handle's stream and, with --pipelined, every lane
     CHECK_HIP(hipStreamSynchronize(side));
-    ms[(size_t)d] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::vector<uint8_t> host((size_t)F * lout.frame_bytes);
-    CHECK_HIP(hipMemcpy(host.data(), d_out[(steps - 1) & 1], host.size(), hipMemcpyDeviceToHost));
+    ms[(size_t)w] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<uint8_t> host((size_t)nf * lout.frame_bytes);
+    if (nf > 0) CHECK_HIP(hipMemcpy(host.data(), d_out[(size_t)(gather ? buffer_of_step(steps - 1) : (steps - 1) % nbuf)], host.size(), hipMemcpyDeviceToHost));
     unsigned long long s = 0;
     for (uint8_t v : host) s += v;
-    sums[(size_t)d] = s;
+    sums[(size_t)w] = s;
     VideoFrameTransform_delete(t);
     CHECK_HIP(hipFree(d_in));
-    for (int b = 0; b < 2; b++) CHECK_HIP(hipFree(d_out[b]));
+    for (int b = 0; b < nbuf; b++) CHECK_HIP(hipFree(d_out[(size_t)b]));
     if (sink) CHECK_HIP(hipFree(sink));
   };
   std::vector<std::thread> th;
-  for (int d = 0; d < ndev; d++) th.emplace_back(worker, d);
+  for (int w = 0; w < workers; w++) th.emplace_back(worker, w);
   for (auto& x : th) x.join();
   double worst = 0;
-  for (int d = 0; d < ndev; d++) {
-    printf("device %d: %.4f ms per step of %d frames, output checksum %llu\n", d, ms[(size_t)d] / steps, F, sums[(size_t)d]);
-    worst = ms[(size_t)d] > worst ? ms[(size_t)d] : worst;
+  int frames_per_step = 0;
+  for (int w = 0; w < workers; w++) {
+    printf("device %d (worker %d): %.4f ms per step of %d frames [%d, %d), output checksum %llu\n", device_of[(size_t)w], w,
+           ms[(size_t)w] / steps, hi[(size_t)w] - lo[(size_t)w], lo[(size_t)w], hi[(size_t)w], sums[(size_t)w]);
+    worst = ms[(size_t)w] > worst ? ms[(size_t)w] : worst;
+    frames_per_step += hi[(size_t)w] - lo[(size_t)w];
   }
-  printf("%d device(s), %s: %.1f Mpix/s (%.0f frames/s)\n", ndev, gather ? "outputs gathered on device 0" : "compute only",
-         (double)ndev * F * steps / (worst * 1e-3) * 1.572864, (double)ndev * F * steps / (worst * 1e-3));
+  printf("%d worker(s) on %d device(s), %s scaling, %s%s: %.1f Mpix/s (%.0f frames/s), %.4f ms per step of %d frames\n", workers, ndev,
+         total_frames > 0 ? "strong" : "weak", gather ? "outputs gathered on worker 0" : "compute only",
+         depth > 0 ? ", pipelined calls" : "", (double)frames_per_step * steps / (worst * 1e-3) * 1.572864,
+         (double)frames_per_step * steps / (worst * 1e-3), worst / steps, frames_per_step);
   if (gather)
     for (ncclComm_t c : comms) ncclCommDestroy(c);
   return 0;

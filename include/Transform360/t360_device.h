@@ -61,6 +61,25 @@ int T360_transformFrames(VideoFrameTransform* transform,
                          uint8_t* d_out, int64_t out_frame_bytes,
                          int n_frames, const T360PlaneDesc* planes, int n_planes);
 
+/* The same work as T360_transformFrames for a STREAM of batches: consecutive pipelined calls are taken to be
+ * independent of each other (they read and write different buffers, as the batches of a frame stream do) and are issued
+ * round-robin on `depth` internal HIP streams ("lanes") of the handle, so that the workgroups of call k+1 start while
+ * the last ones of call k drain (a launch of the tiled gather ends on a partly empty GPU, and a short batch -- 8 frames
+ * per GPU when 64 are sharded over 8 GPUs, SURVEY.md 8e -- spends a third of its life filling and draining).
+ *   - ordering IN: every pipelined call starts after everything queued on the handle's stream at the time of the call;
+ *   - ordering OUT: nothing waits for a lane by itself.  T360_pipelineJoin makes the handle's stream wait (on the device,
+ *     the host does not block) for every pipelined call issued so far; T360_synchronize blocks the host until the
+ *     handle's stream AND all lanes are idle;
+ *   - calls k and k + depth run on the same lane, in order: an output buffer may be reused every `depth` calls.
+ * depth: 1..4, default 2 (set with T360_setPipelineDepth before the first pipelined call or after a join).
+ * Same arithmetic, same kernels, same return convention as T360_transformFrames. */
+int T360_transformFramesPipelined(VideoFrameTransform* transform,
+                                  const uint8_t* d_in, int64_t in_frame_bytes,
+                                  uint8_t* d_out, int64_t out_frame_bytes,
+                                  int n_frames, const T360PlaneDesc* planes, int n_planes);
+int T360_setPipelineDepth(VideoFrameTransform* transform, int depth);
+int T360_pipelineJoin(VideoFrameTransform* transform);
+
 /* Low-pass stage only (reference filterPlane, VideoFrameTransform.cpp:621-704) on one
  * device-resident plane; asynchronous.  For parity tests of the segmented filter. */
 int T360_filterPlane(VideoFrameTransform* transform, const uint8_t* d_in, uint8_t* d_out,

@@ -118,6 +118,16 @@ extern "C" long long t360_plan_verify(const t360::LutEntry* lut, int dw, int dh,
       case kTileScatter: w = 128; h = 16; lanes = 512; break;
       default: complain("unknown tile kind", ti, t.ox, t.oy); continue;
     }
+    if (t.kind == kTileScatter || (npx == 4 && !(t.flags & kTilePartial))) {
+      // tiles that take the kernel's dword store: after the 4x4 byte transpose a lane stores pixels that four lanes
+      // computed, so every quad of lanes must be entirely live or (scatter tiles only) entirely dead
+      for (int q = 0; q < lanes / 4; q++) {
+        int live = 0;
+        for (int l = 0; l < 4; l++)
+          for (int p = 0; p < 4; p++) live += (words[(size_t)(4 * q + l) * per_lane + p] >> 31) == 0;
+        if (live != 16 && !(live == 0 && t.kind == kTileScatter)) complain("partly live quad in a dword-stored tile", ti, t.ox, t.oy);
+      }
+    }
     for (int tid = 0; tid < lanes; tid++)
       for (int p = 0; p < npx; p++) {
         int px, py;

@@ -256,6 +256,71 @@ def test_batch_equals_per_plane_calls(T, oracle_mod):
         _batch_case(T, oracle_mod, ov)
 
 
+@pytest.mark.parametrize("ov,depth", [(dict(enable_low_pass_filter=0), 2),
+                                      (dict(num_vertical_segments=5, num_horizontal_segments=4), 3),
+                                      (dict(enable_low_pass_filter=0, width_scale_factor=2.0, height_scale_factor=2.0), 4)])
+def test_pipelined_calls_equal_plain_calls_and_the_oracle(ov, depth, T, oracle_mod):
+    """T360_transformFramesPipelined: a stream of independent batches issued round-robin on the handle's internal streams
+    (each lane has its own low-pass / supersample scratch planes).  Seven batches of different frames, output buffers
+    reused every `depth` calls as the header allows: every batch equals the plain T360_transformFrames result bit for
+    bit, and one batch is compared with the oracle directly; pipelineJoin() orders a consumer on the handle's stream."""
+    import torch
+    O = oracle_mod
+    in_w, in_h, out_w, out_h = 960, 480, 384, 256
+    nb, n = 7, 3
+    ctx = filter_defaults(**ov)
+    lin, lout = T.FrameLayout(in_w, in_h), T.FrameLayout(out_w, out_h)
+    batches = []
+    for b in range(nb):
+        d = torch.empty(n * lin.frame_bytes, dtype=torch.uint8, device="cuda")
+        for k in range(n):
+            T.fill_noise(d[k * lin.frame_bytes:(k + 1) * lin.frame_bytes], T.frame_seed(100 * b + k))
+        batches.append(d)
+    torch.cuda.synchronize()
+    with T.VideoFrameTransform(ctx) as t:
+        for idx, k in ((0, 0), (1, 1)):
+            assert t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+        descs = t.plane_descs(lin, lout)
+        assert t.setStream(torch.cuda.current_stream())
+        want = []
+        for b in range(nb):
+            o_ = torch.zeros(n * lout.frame_bytes, dtype=torch.uint8, device="cuda")
+            assert t.transformFrames(batches[b], lin.frame_bytes, o_, lout.frame_bytes, n, descs)
+            want.append(o_)
+        assert t.synchronize()
+        assert not t.setPipelineDepth(0) and not t.setPipelineDepth(5)
+        assert t.setPipelineDepth(depth)
+        outs = [torch.zeros(n * lout.frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        got = []
+        for b in range(nb):
+            buf = outs[b % depth]
+            if b >= depth:
+                # the buffer's previous content must be saved before its lane overwrites it: order the copy after the
+                # pipelined calls issued so far
+                assert t.pipelineJoin()
+                got.append(buf.clone())
+            assert t.transformFramesPipelined(batches[b], lin.frame_bytes, buf, lout.frame_bytes, n, descs)
+        assert t.pipelineJoin()
+        for b in range(nb - depth, nb):
+            got.append(outs[b % depth].clone())
+        assert t.synchronize()
+        torch.cuda.synchronize()
+        for b in range(nb):
+            assert torch.equal(got[b], want[b]), "pipelined batch %d differs from the plain call" % b
+    o = O.Oracle(ctx, threads=4)
+    for idx, k in ((0, 0), (1, 1)):
+        assert o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
+    h_in, h_out = batches[nb - 1].cpu().numpy(), got[nb - 1].cpu().numpy()
+    for k in range(n):
+        fin = h_in[k * lin.frame_bytes:(k + 1) * lin.frame_bytes]
+        fout = h_out[k * lout.frame_bytes:(k + 1) * lout.frame_bytes]
+        for p in range(3):
+            ref = np.zeros((lout.dims[p][1], lout.dims[p][0]), np.uint8)
+            assert o.transformFramePlane(lin.plane_view(fin, p), ref, 1 if p else 0, p)
+            assert np.array_equal(lout.plane_view(fout, p), ref), (k, p)
+    o.close()
+
+
 @pytest.mark.parametrize("interp", [NEAREST, LINEAR, LANCZOS4])
 def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
     # the LDS-tiled DMA-ring kernel instantiated for 1-, 2- and 8-tap stencils (frames 16-byte friendly)

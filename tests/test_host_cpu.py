@@ -272,3 +272,24 @@ def test_bench_rank_function_world_size_2_gloo():
     assert g["bytes_to_rank0_per_step"] > 0 and g["ms_per_step"] > 0 and "gloo" in g["collective"]
     x = rec["scatter_gather"]
     assert x["bytes_from_rank0_per_step"] > x["bytes_to_rank0_per_step"] > 0 and x["ms_per_step"] > 0
+
+
+def test_native_multi_gpu_driver_bookkeeping(tmp_path):
+    """examples/t360_shard_plan.h -- the frame ranges, the per-step send / recv lists and the buffer alternation of the
+    native multi-GPU driver (examples/t360_multi_gpu.cpp) -- compiled with g++ and checked without HIP or RCCL
+    (tests/c/shard_plan_test.cpp): every frame owned once, every send met by one receive of its size, the sink gap-free."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shard_plan_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "c", "shard_plan_test.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "shard plan ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_states_the_cores_it_may_use():
+    import bench
+    a = bench.host_cpu_allowance()
+    assert 1 <= a["usable_cores"] <= a["logical_cores_of_the_node"]
+    assert a["sched_affinity_cores"] is None or a["usable_cores"] <= a["sched_affinity_cores"]

@@ -28,9 +28,15 @@ def kernels(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     out = str(tmp_path_factory.mktemp("isa") / "remap_tiled.s")
-    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + CSRC, "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "t360_remap_tiled.hip")],
-                          stderr=subprocess.DEVNULL)
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, "t360_remap_tiled.hip")]
+    r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        # a ROCm install without the gfx950 target cannot produce the ISA to inspect: skip, do not error;
+        # a genuine compile error of the kernel file still fails __graft_entry__.build() and the library's Makefile
+        if "gfx950" in r.stderr and ("unsupported" in r.stderr.lower() or "unknown target" in r.stderr.lower() or "invalid" in r.stderr.lower()):
+            pytest.skip("this hipcc has no gfx950 target")
+        raise AssertionError("hipcc -S failed:\n" + r.stderr[-2000:])
     text = open(out).read()
     bodies = {}
     for m in re.finditer(r"^(_ZN4t360\S*remap_tiled_kernelILi(\d+)ELi(\d+)ELi(\d+)E[^:\s]*):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):

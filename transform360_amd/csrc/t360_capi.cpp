@@ -112,6 +112,25 @@ T360_EXPORT int T360_transformFrames(VideoFrameTransform* t, const uint8_t* d_in
   });
 }
 
+T360_EXPORT int T360_transformFramesPipelined(VideoFrameTransform* t, const uint8_t* d_in, int64_t in_frame_bytes,
+                                              uint8_t* d_out, int64_t out_frame_bytes, int n_frames,
+                                              const T360PlaneDesc* planes, int n_planes) {
+  if (!t) return 0;
+  return guarded("T360_transformFramesPipelined", [&] {
+    return t->transformFramesPipelined(d_in, in_frame_bytes, d_out, out_frame_bytes, n_frames, planes, n_planes);
+  });
+}
+
+T360_EXPORT int T360_setPipelineDepth(VideoFrameTransform* t, int depth) {
+  if (!t) return 0;
+  return guarded("T360_setPipelineDepth", [&] { return t->setPipelineDepth(depth); });
+}
+
+T360_EXPORT int T360_pipelineJoin(VideoFrameTransform* t) {
+  if (!t) return 0;
+  return guarded("T360_pipelineJoin", [&] { return t->pipelineJoin(); });
+}
+
 T360_EXPORT int T360_filterPlane(VideoFrameTransform* t, const uint8_t* d_in, uint8_t* d_out, int width,
                                  int height, int in_stride, int out_stride, int map_index) {
   if (!t) return 0;

@@ -447,12 +447,15 @@ __device__ __forceinline__ uint32_t gather(const PixelSetup<NPX, KS>& s, const u
 // the deferred store of one frame's value
 template <int NPX, int KS>
 __device__ __forceinline__ void emit(const PixelSetup<NPX, KS>& s, uint32_t val, uint8_t* __restrict__ dbase, uint32_t doff,
-                                     int dstride, bool dword_store) {
+                                     int dstride, bool dword_store, bool all_live) {
   dbase = T360_UNIFORM(dbase);
   if (NPX == 4) {
     if (dword_store) {
-      // (a scatter tile's missing blocks have dead pixel words on all four lanes of the quad: they store nothing)
-      if (s.live[0]) store_dword<(KS != 1) && T360_STORE_NT>(dbase, doff, val);
+      // After the quad transpose a lane stores pixels that came from four lanes.  Rectangular tiles take the dword path
+      // only when they are not partial (all_live, wave-uniform: every quad is whole); a scatter tile's missing blocks
+      // have dead pixel words on all four lanes of the quad and store nothing (tests/plan_sim checks that every quad of
+      // a scatter plan is entirely live or entirely dead).
+      if (all_live || s.live[0]) store_dword<(KS != 1) && T360_STORE_NT>(dbase, doff, val);
     } else {
 #pragma unroll
       for (int p = 0; p < NPX; p++)
@@ -631,6 +634,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
   pin_pixels<NPX, KS>(px);
   T360_MARK(a, 2);  // pixel setup here (and, with tracing on, the prologue DMA landed)
   const bool dword_store = NPX == 4 && (!(t.flags & kTilePartial) || t.kind == kTileScatter) && pl.dst_dword_ok;
+  const bool all_live = t.kind != kTileScatter;  // (of the dword path: partial rectangular tiles store bytes)
   const uint32_t doff = out_pos<NPX>(pl, t, dword_store, tf.origin);
   uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);  // the store uses SGPR base + VGPR offset
   uint32_t pending = 0;
@@ -657,7 +661,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
       if (!T360_DBG(a, 7)) frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */ \
       T360_PHASE(1);                                                                                       \
       if (i + S > 0) {                                                                                     \
-        if (has_px && !T360_DBG(a, 8)) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);       \
+        if (has_px && !T360_DBG(a, 8)) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store, all_live);       \
         d += pl.dst_frame_bytes;                                                                           \
       }                                                                                                    \
       if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
@@ -671,7 +675,7 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
     T360_STEP(0) T360_STEP(1) T360_STEP(2) T360_STEP(3)
 #undef T360_STEP
   }
-  if (nf > 0 && has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store);
+  if (nf > 0 && has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store, all_live);
 #ifdef T360_INSTRUMENT
   if (a.phases && (wave == 0 || wave == WAVES - 1) && lane == 0) {
     unsigned long long* o = a.phases + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);

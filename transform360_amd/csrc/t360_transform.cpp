@@ -223,6 +223,14 @@ VideoFrameTransform::~VideoFrameTransform() {
     if (lp_join_[k]) (void)hipEventDestroy(lp_join_[k]);
   }
   if (lp_fork_) (void)hipEventDestroy(lp_fork_);
+  for (int k = 0; k < kMaxLanes; k++) {
+    if (pipe_streams_[k]) {
+      (void)hipStreamSynchronize(pipe_streams_[k]);
+      (void)hipStreamDestroy(pipe_streams_[k]);
+    }
+    if (pipe_done_[k]) (void)hipEventDestroy(pipe_done_[k]);
+  }
+  if (pipe_fork_) (void)hipEventDestroy(pipe_fork_);
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -235,21 +243,93 @@ bool VideoFrameTransform::check(hipError_t e, const char* what) const {
 
 bool VideoFrameTransform::setStream(void* s) {
   DeviceGuard g(device_);
-  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize") || !drainLanes()) return false;
   stream_ = static_cast<hipStream_t>(s);  // nullptr = HIP's NULL stream
   return true;
 }
 
 bool VideoFrameTransform::useOwnStream() {
   DeviceGuard g(device_);
-  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
+  if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize") || !drainLanes()) return false;
   stream_ = own_stream_;
   return true;
 }
 
 bool VideoFrameTransform::synchronize() {
   DeviceGuard g(device_);
-  return check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return check(hipStreamSynchronize(stream_), "hipStreamSynchronize") && drainLanes();
+}
+
+// ---- T360_transformFramesPipelined: a stream of independent batches on pipe_depth_ internal streams ----
+bool VideoFrameTransform::ensureLanes() {
+  if (!pipe_fork_ && !check(hipEventCreateWithFlags(&pipe_fork_, hipEventDisableTiming), "hipEventCreate")) return false;
+  for (int k = 0; k < pipe_depth_; k++) {
+    if (!pipe_streams_[k] && !check(hipStreamCreateWithFlags(&pipe_streams_[k], hipStreamNonBlocking), "hipStreamCreate")) return false;
+    if (!pipe_done_[k] && !check(hipEventCreateWithFlags(&pipe_done_[k], hipEventDisableTiming), "hipEventCreate")) return false;
+  }
+  return true;
+}
+
+bool VideoFrameTransform::drainLanes() {
+  bool ok = true;
+  for (int k = 0; k < kMaxLanes; k++)
+    if (pipe_streams_[k] && pipe_busy_[k]) {
+      ok = check(hipStreamSynchronize(pipe_streams_[k]), "hipStreamSynchronize") && ok;
+      pipe_busy_[k] = false;
+    }
+  return ok;
+}
+
+bool VideoFrameTransform::setPipelineDepth(int depth) {
+  if (!ok_) return false;
+  if (depth < 1 || depth > kMaxLanes) {
+    printf("transform360: T360_setPipelineDepth: depth must be 1..%d\n", kMaxLanes);
+    return false;
+  }
+  DeviceGuard g(device_);
+  // the lane of call k is k mod depth: changing the modulus in mid-sequence would break "an output buffer may be reused
+  // every depth calls", so the sequence ends here
+  if (!drainLanes()) return false;
+  pipe_depth_ = depth;
+  pipe_next_ = 0;
+  return true;
+}
+
+bool VideoFrameTransform::pipelineJoin() {
+  if (!ok_) return false;
+  DeviceGuard g(device_);
+  for (int k = 0; k < kMaxLanes; k++)
+    if (pipe_streams_[k] && pipe_busy_[k]) {
+      if (!check(hipEventRecord(pipe_done_[k], pipe_streams_[k]), "hipEventRecord") ||
+          !check(hipStreamWaitEvent(stream_, pipe_done_[k], 0), "hipStreamWaitEvent"))
+        return false;
+      pipe_busy_[k] = false;
+    }
+  pipe_next_ = 0;
+  return true;
+}
+
+bool VideoFrameTransform::transformFramesPipelined(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
+                                                   int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes,
+                                                   int n_planes) {
+  if (!ok_) return false;
+  DeviceGuard g(device_);
+  if (!ensureLanes()) return false;
+  const int lane = pipe_next_;
+  hipStream_t ls = pipe_streams_[lane];
+  // ordering IN: the lane waits (on the device) for what is queued on the handle's stream right now
+  if (!check(hipEventRecord(pipe_fork_, stream_), "hipEventRecord") ||
+      !check(hipStreamWaitEvent(ls, pipe_fork_, 0), "hipStreamWaitEvent"))
+    return false;
+  hipStream_t saved = stream_;
+  stream_ = ls;
+  scratch_ = 1 + lane;
+  const bool ok = transformFrames(d_in, in_frame_bytes, d_out, out_frame_bytes, n_frames, planes, n_planes);
+  stream_ = saved;
+  scratch_ = 0;
+  pipe_busy_[lane] = true;
+  pipe_next_ = (lane + 1) % pipe_depth_;
+  return ok;
 }
 
 bool VideoFrameTransform::ensureWeights() {
@@ -882,11 +962,11 @@ bool VideoFrameTransform::runPlanesScaled(const PlaneJob* jobs, int njobs, int n
     offs[(size_t)k] = total;
     total += (size_t)strides[(size_t)k] * p.map_h * (size_t)n_frames;
   }
-  if (!scaled_.reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(scaled)");
+  if (!scaled_[scratch_].reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(scaled)");
   for (int k = 0; k < njobs; k++) {
     const PlaneState& p = planes_[jobs[k].idx];
     PlaneJob& j = inner[(size_t)k];
-    j.out = scaled_.as<uint8_t>() + offs[(size_t)k];
+    j.out = scaled_[scratch_].as<uint8_t>() + offs[(size_t)k];
     j.out_w = p.map_w;
     j.out_h = p.map_h;
     j.out_stride = strides[(size_t)k];
@@ -996,14 +1076,14 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       offs[(size_t)k] = total;
       total += (size_t)bstride * jobs[k].in_h * (size_t)n_frames;
     }
-    if (!blurred_.reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
+    if (!blurred_[scratch_].reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
     const bool side = njobs > 1 && njobs <= 4;  // planes 1.. on their own streams beside plane 0
     if (side && !check(hipEventRecord(lp_fork_, stream_), "hipEventRecord")) return false;
     for (int k = 0; k < njobs; k++) {
       const PlaneJob& j = jobs[k];
       const int bstride = (j.in_w + 255) & ~255;
       const int64_t plane_bytes = (int64_t)bstride * j.in_h;
-      uint8_t* bl = blurred_.as<uint8_t>() + offs[(size_t)k];
+      uint8_t* bl = blurred_[scratch_].as<uint8_t>() + offs[(size_t)k];
       hipStream_t st = stream_;
       if (side && k > 0) {
         st = lp_streams_[k - 1];
@@ -1031,6 +1111,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // the waves of an 8-wave workgroup would carry no pixels: 4-wave workgroups, four to a CU, at every batch length;
   // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, tools/experiments_r04/call8.sh)
   bool small = small_batch_ > 0 && (n_frames < small_batch_ || interp == NEAREST) && interp != LANCZOS4 && waves_ != 4;
+  // the planner's host copy of a map's sample LUT lives for this call only, and is fetched once per map even when both
+  // plans of the map end up being tried below
+  std::vector<LutEntry> host_luts[kMaxMaps];
+  auto ensureGatherPlan = [&](PlaneState& ps, bool sm) { return this->ensureGatherPlan(ps, sm, &host_luts[&ps - planes_]); };
   for (int k = 0; k < njobs; k++)
     if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], small)) return false;
   // (a map the 4-wave planner could not take but the 8-wave one can: every plane of the call then uses the latter)
@@ -1206,15 +1290,16 @@ bool VideoFrameTransform::buildGatherPlan(PlaneState& p, const MapGenParams& P, 
   return true;
 }
 
-bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small) {
+bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small, std::vector<LutEntry>* lut_of_this_call) {
   PlaneState::GatherPlan& g = small ? p.plan_small : p.plan;
   if (g.valid || g.tried || p.plan_ks == 0) return true;
   g.tried = true;  // not plannable stays not plannable: the general gather serves the map
-  // The planner works on a host copy of the sample LUT.  It is fetched from device memory HERE and lives for this
-  // call only (12.6 MB for the 4K luma map, up to 2^28 entries x 8 B for the largest map the ABI admits): a handle
-  // never holds a host copy between calls, whichever regimes it ends up planning.
-  std::vector<LutEntry> host_lut;
-  {
+  // The planner works on a host copy of the sample LUT.  It is fetched from device memory HERE and lives for the
+  // transform call that needs it only (12.6 MB for the 4K luma map, up to 2^28 entries x 8 B for the largest map the
+  // ABI admits): a handle never holds a host copy between calls, whichever regimes it ends up planning;
+  // a call that plans both regimes of one map fetches it once.
+  std::vector<LutEntry>& host_lut = *lut_of_this_call;
+  if (host_lut.size() != (size_t)p.map_w * (size_t)p.map_h) {
     const size_t n = (size_t)p.map_w * (size_t)p.map_h;
     try {
       host_lut.resize(n);

@@ -53,6 +53,11 @@ class VideoFrameTransform {
   bool synchronize();
   bool transformFrames(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
                        int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes, int n_planes);
+  // a stream of independent batches, round-robin over pipe_depth_ internal streams (t360_device.h)
+  bool transformFramesPipelined(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
+                                int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes, int n_planes);
+  bool setPipelineDepth(int depth);
+  bool pipelineJoin();
   bool filterPlane(const uint8_t* d_in, uint8_t* d_out, int width, int height, int in_stride,
                    int out_stride, int map_index);
   bool getMapSize(int idx, int* w, int* h) const;
@@ -106,7 +111,7 @@ class VideoFrameTransform {
   bool ensureWeights();
   bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
   bool buildGatherPlan(PlaneState& p, const t360::MapGenParams& P, int in_w, int in_h);
-  bool ensureGatherPlan(PlaneState& p, bool small);
+  bool ensureGatherPlan(PlaneState& p, bool small, std::vector<t360::LutEntry>* lut_of_this_call);
   // all-device core: a set of planes of n frames
   struct PlaneJob {
     const uint8_t* in;
@@ -160,8 +165,20 @@ class VideoFrameTransform {
   void setLastKernel(const char* name) { snprintf(last_kernel_, sizeof(last_kernel_), "%s", name); }
   bool use_fast_lowpass_ = true;
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
-  t360::DeviceBuffer blurred_;  // low-pass output, n_frames planes
-  t360::DeviceBuffer scaled_;   // supersampled (warp-map sized) planes before the INTER_AREA shrink
+  // scratch planes: [0] for the calls on the handle's stream, [1 + lane] for the pipelined calls of that lane (calls on
+  // different lanes overlap on the device and must not share intermediates)
+  static constexpr int kMaxLanes = 4;
+  t360::DeviceBuffer blurred_[1 + kMaxLanes];  // low-pass output, n_frames planes
+  t360::DeviceBuffer scaled_[1 + kMaxLanes];   // supersampled (warp-map sized) planes before the INTER_AREA shrink
+  int scratch_ = 0;                            // which set the running call uses
+  // T360_transformFramesPipelined: lanes are created by the first pipelined call
+  int pipe_depth_ = 2, pipe_next_ = 0;
+  hipStream_t pipe_streams_[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pipe_done_[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pipe_fork_ = nullptr;
+  bool pipe_busy_[kMaxLanes] = {false, false, false, false};  // work issued on the lane since the last join
+  bool ensureLanes();
+  bool drainLanes();  // host-side wait for every lane
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path: device side
   t360::HostStager stager_;                  // ... the copies (contiguous where the strides allow; nothing is pinned or cached)
 };

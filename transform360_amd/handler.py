@@ -128,6 +128,19 @@ class VideoFrameTransform:
             self._h, d_in.data_ptr(), in_frame_bytes, d_out.data_ptr(), out_frame_bytes, n_frames,
             descs, len(descs)))
 
+    def transformFramesPipelined(self, d_in, in_frame_bytes, d_out, out_frame_bytes, n_frames, descs):
+        """T360_transformFramesPipelined: the same work for a stream of independent batches, round-robin over the handle's
+        internal streams; nothing is complete before pipelineJoin() (device-side) or synchronize() (host-side)."""
+        return bool(self._l.T360_transformFramesPipelined(
+            self._h, d_in.data_ptr(), in_frame_bytes, d_out.data_ptr(), out_frame_bytes, n_frames,
+            descs, len(descs)))
+
+    def setPipelineDepth(self, depth):
+        return bool(self._l.T360_setPipelineDepth(self._h, depth))
+
+    def pipelineJoin(self):
+        return bool(self._l.T360_pipelineJoin(self._h))
+
     def filterPlane(self, d_in, d_out, map_index):
         ip, iw, ih, istride = _plane_ptr(d_in)
         op, _, _, ostride = _plane_ptr(d_out)
