@@ -57,7 +57,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REPEATS = 5
-RING_BYTES = 320 << 20     # distinct input bytes the timed steps cycle through: more than the 256 MB Infinity Cache
+RING_BYTES = 1400 << 20    # distinct input bytes the timed steps cycle through: several times the 256 MB Infinity Cache, and at
+                           # least two batches (64 frames of config 2 are 708 MB: reading the SAME 708 MB every step measured 1 %
+                           # faster than a ring of two or three batches, and let overlapping launches share lines: round 5, call 5)
 CLOCK_WARMUP_S = 0.4   # untimed load before the contract's warm-up steps (GPU clocks ramp)
 
 
@@ -313,7 +315,11 @@ class HipPath:
         from transform360_amd import handler
         self.torch, self.handler = torch, handler
         self.wl, self.ctx, self.lin, self.lout, self.F, self.rank = wl, ctx, lin, lout, F, rank
-        self.stream = torch.cuda.current_stream()
+        # a stream of our own (non-blocking) as torch's current stream: the legacy NULL stream orders against every blocking
+        # stream of the process, and the library's idle-stream test before a pipelined call (hipStreamQuery) is then not
+        # the cheap question it is for an ordinary stream
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
         torch.zeros(1, device="cuda")  # the HIP runtime's own start-up (100+ ms, once per process) is not map generation
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -378,6 +384,38 @@ class HipPath:
         k = getattr(self, "k", 0)
         assert self.t.transformFramesPipelined(self.d_in if inp is None else inp, self.lin.frame_bytes,
                                                self.pipe_outs[k % self.pipe_depth], self.lout.frame_bytes, n_frames, self.descs)
+
+    def fast_steps(self, n_frames, steps, groups, pipelined):
+        """The timed loop with everything Python does per step taken out of it: raw pointers and the ctypes call are
+        prepared once, the loop is `for a in calls: f(*a)`.  A step of 8 frames is 35-45 us of GPU time and the generic
+        loop above (tensor slices, data_ptr(), attribute lookups) costs 15-25 us of host time per step -- host-bound for
+        pipelined short steps; a C++ caller (examples/t360_multi_gpu.cpp) has no such cost.  Same calls, same work."""
+        import ctypes as C
+        L = self.t._l
+        f = L.T360_transformFramesPipelined if pipelined else L.T360_transformFrames
+        base = self.ring.data_ptr()
+        outs = self.pipe_outs if pipelined else [self.d_out]
+        h, nd = self.t._h, len(self.descs)
+        calls = [(h, C.c_void_p(base + (k % groups) * n_frames * self.lin.frame_bytes), C.c_int64(self.lin.frame_bytes),
+                  C.c_void_p(outs[k % len(outs)].data_ptr()), C.c_int64(self.lout.frame_bytes), n_frames, self.descs, nd)
+                 for k in range(steps)]
+
+        if pipelined:
+            # the K pipelined calls of the timed region issued by the library's own loop (one ctypes call)
+            ins = (C.c_void_p * steps)(*[a[1].value for a in calls])
+            dsts = (C.c_void_p * steps)(*[a[3].value for a in calls])
+            many = L.T360_transformFramesPipelinedMany
+
+            def run_many():
+                if not many(h, steps, ins, self.lin.frame_bytes, dsts, self.lout.frame_bytes, n_frames, self.descs, nd):
+                    raise RuntimeError("transform call failed")
+            return run_many
+
+        def run():
+            for a in calls:
+                if not f(*a):
+                    raise RuntimeError("transform call failed")
+        return run
 
     def new_events(self, n):
         return [(self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -566,6 +604,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
         groups = max(1, ring_frames // n_frames) if rotate else 1
         ring = getattr(path, "ring", None) if groups > 1 else None
         out = []
+        fast = None
+        if after_step is None and before_step is None and not alternate and hasattr(path, "fast_steps"):
+            fast = path.fast_steps(n_frames, steps, groups if ring is not None else 1, pipelined)
         for _ in range(REPEATS):
             # ONE event pair around the K launches of the timed region (on the stream the kernels run on): the average
             # launch duration is its span / K, gaps between launches included.  A pair per step cost 7 us per step -- 3 %
@@ -575,7 +616,9 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             t0 = time.perf_counter()
             if events is not None:
                 path.mark(events, 0)
-            for k in range(steps):
+            if fast is not None:
+                fast()
+            for k in range(steps if fast is None else 0):
                 path.k = k  # the double-buffered legs pick their buffers from the step number of THIS timed region
                 if before_step is not None:
                     before_step(k)
@@ -643,6 +686,26 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     elapsed, launch_ms = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     kernel_name = path.kernel_name()
 
+    pipelined = None
+    if path.name == "hip" and not args.no_two_streams:
+        path.set_pipeline(args.pipeline_depth)
+        for k in range(2 * args.pipeline_depth):
+            path.k = k
+            path.step_pipelined(F)
+        path.sync()
+        pruns = timed_run(F, args.steps, False, rotate=rotate, pipelined=True)
+        p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
+        pipelined = {"what": "the headline steps through T360_transformFramesPipelined (one handle, %d internal streams, independent "
+                             "batches, %d output buffers): step k+1 starts while step k drains; NOT the `value` above, whose "
+                             "launches are back to back on one stream" % (args.pipeline_depth, args.pipeline_depth),
+                     "ms_per_step": round(p_el / args.steps * 1e3, 4),
+                     "value": round(args.steps * F * world / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
+                     "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in pruns]}
+        path.step(F)  # d_out holds group 0's full-batch result again
+        path.sync()
+
+    pipelined_64 = pipelined["ms_per_step"] * 1e-3 * args.steps if pipelined is not None and F == 64 else None
+
     # BASELINE configs[4] as written: 64 frames in total, frame-sharded -> ceil(64 / N) per rank (strong scaling).  No
     # events inside: a step of 8 frames is 40 us and two event records per step are 10 % of it.
     strong = None
@@ -698,30 +761,20 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                     path.step_pipelined(8)
                 path.sync()
                 e8p = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate, pipelined=True))[REPEATS // 2]
-                strong["projected_8_gpus"]["pipelined_ms_per_step"] = round(e8p / args.steps * 1e3, 4)
-                strong["projected_8_gpus"]["pipelined_speedup_over_1_gpu"] = round(s_el / e8p, 2)
-                strong["projected_8_gpus"]["pipelined_what"] = ("8-frame steps through T360_transformFramesPipelined (depth %d) against "
-                                                                "this line's one-stream 64-frame step" % args.pipeline_depth)
+                p8 = strong["projected_8_gpus"]
+                p8["one_stream_ms_per_step"], p8["one_stream_speedup_over_1_gpu"] = p8["ms_per_step"], p8["speedup_over_1_gpu"]
+                p8["ms_per_step"] = round(e8p / args.steps * 1e3, 4)
+                p8["speedup_over_1_gpu"] = round(s_el / e8p, 2)
+                p8["what"] = ("one GPU's share at 8 GPUs (8 frames per step, input rotating through HBM) timed on this GPU the way a GPU of "
+                              "the node would be driven: a stream of 8-frame steps through T360_transformFramesPipelined (one handle, "
+                              "%d internal streams; the K calls issued by T360_transformFramesPipelinedMany).  speedup = this line's "
+                              "one-stream 64-frame step time / that 8-frame step time; one_stream_* = the same steps as plain "
+                              "T360_transformFrames calls back to back.  No inter-GPU traffic on the path: frames are sharded "
+                              "(SURVEY 8e)" % args.pipeline_depth)
+                if pipelined_64 is not None:
+                    p8["speedup_over_pipelined_1_gpu"] = round(pipelined_64 / e8p, 2)
         if f5 * world != 64:
             strong["note"] = "64 frames do not divide over %d ranks (or --frames < 64/N): every rank ran %d" % (world, f5)
-
-    pipelined = None
-    if path.name == "hip" and not args.no_two_streams:
-        path.set_pipeline(args.pipeline_depth)
-        for k in range(2 * args.pipeline_depth):
-            path.k = k
-            path.step_pipelined(F)
-        path.sync()
-        pruns = timed_run(F, args.steps, False, rotate=rotate, pipelined=True)
-        p_el = sorted(r[0] for r in pruns)[len(pruns) // 2]
-        pipelined = {"what": "the headline steps through T360_transformFramesPipelined (one handle, %d internal streams, independent "
-                             "batches, %d output buffers): step k+1 starts while step k drains; NOT the `value` above, whose "
-                             "launches are back to back on one stream" % (args.pipeline_depth, args.pipeline_depth),
-                     "ms_per_step": round(p_el / args.steps * 1e3, 4),
-                     "value": round(args.steps * F * world / p_el * out_w * out_h / 1e6, 1), "unit": "Mpix/s",
-                     "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in pruns]}
-        path.step(F)  # d_out holds group 0's full-batch result again
-        path.sync()
 
     two_handles = None
     if args.two_handles and path.name == "hip" and world == 1:

@@ -20,7 +20,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -94,7 +96,7 @@ FrameTransformContext config2() {
 int main(int argc, char** argv) {
   using namespace t360_example;
   const int visible = T360_deviceCount();
-  int ndev = visible, workers = 0, F = 64, steps = 20, total_frames = 0, depth = 0;
+  int ndev = visible, workers = 0, F = 64, steps = 20, total_frames = 0, depth = 0, ring_mb = 320;
   bool gather = false;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = atoi(argv[++i]);
@@ -103,9 +105,10 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--total-frames") && i + 1 < argc) total_frames = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--pipelined") && i + 1 < argc) depth = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--ring-mb") && i + 1 < argc) ring_mb = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--gather")) gather = true;
     else {
-      fprintf(stderr, "usage: t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K] [--pipelined D] [--gather]\n");
+      fprintf(stderr, "usage: t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K] [--pipelined D] [--ring-mb M] [--gather]\n");
       return 2;
     }
   }
@@ -142,6 +145,23 @@ int main(int argc, char** argv) {
   if (gather) CHECK_NCCL(ncclCommInitAll(comms.data(), workers, device_of.data()));
   std::vector<double> ms((size_t)workers);
   std::vector<unsigned long long> sums((size_t)workers);
+  // the workers enter their timed loops TOGETHER (their warm-ups end at different times, and a worker timed while the
+  // others are still warming up -- or already done -- would measure a GPU it has to itself)
+  std::mutex gate_mu;
+  std::condition_variable gate_cv;
+  int gate_waiting = 0, gate_round = 0;
+  auto gate = [&]() {
+    std::unique_lock<std::mutex> lk(gate_mu);
+    const int round = gate_round;
+    if (++gate_waiting == workers) {
+      gate_waiting = 0;
+      gate_round++;
+      gate_cv.notify_all();
+    } else {
+      gate_cv.wait(lk, [&] { return gate_round != round; });
+    }
+  };
+  std::chrono::steady_clock::time_point t_start, t_end;
   auto worker = [&](int w) {
     const int nf = hi[(size_t)w] - lo[(size_t)w];
     CHECK_HIP(hipSetDevice(device_of[(size_t)w]));  // a handle lives on the device that is current when it is created
@@ -157,13 +177,21 @@ int main(int argc, char** argv) {
       exit(1);
     }
     const int nbuf = depth > 2 ? depth : 2;  // an output buffer is reused every `depth` pipelined calls
+    // Input ring: when one step's input is smaller than the 256 MB Infinity Cache (8 frames = 88 MB), the steps rotate
+    // through `groups` batches -- ring_mb of distinct input per worker -- so that no step finds its source in a cache
+    // because the previous one read the same bytes (bench.py does the same; group 0 holds the stream's own frames).
+    const int64_t step_in = (int64_t)(nf > 0 ? nf : 1) * lin.frame_bytes;
+    const int groups = step_in < ((int64_t)ring_mb << 20) ? (int)((((int64_t)ring_mb << 20) + step_in - 1) / step_in) : 1;
     uint8_t *d_in, *sink = nullptr;
     std::vector<uint8_t*> d_out((size_t)nbuf);
-    CHECK_HIP(hipMalloc(&d_in, (size_t)(nf > 0 ? nf : 1) * lin.frame_bytes));
+    CHECK_HIP(hipMalloc(&d_in, (size_t)groups * step_in));
     for (int b = 0; b < nbuf; b++) CHECK_HIP(hipMalloc(&d_out[(size_t)b], (size_t)(nf > 0 ? nf : 1) * lout.frame_bytes));
     if (gather && w == 0) CHECK_HIP(hipMalloc(&sink, (size_t)sink_bytes));
-    for (int j = 0; j < nf; j++)  // frame j of worker w = frame lo_w + j of the synthetic stream (bench.py's seeds)
-      T360_fillNoise(d_in + (size_t)j * lin.frame_bytes, lin.frame_bytes, (0x360ull ^ ((unsigned long long)(lo[(size_t)w] + j) << 40)) & 0xffffffffffffffffull, stream);
+    for (int j = 0; j < nf * groups; j++) {  // frame j < nf of worker w = frame lo_w + j of the synthetic stream (bench.py's seeds)
+      const unsigned long long fr = j < nf ? (unsigned long long)(lo[(size_t)w] + j) : 1000000ull + (unsigned long long)w * 100000ull + (unsigned long long)j;
+      T360_fillNoise(d_in + (size_t)j * lin.frame_bytes, lin.frame_bytes, 0x360ull ^ (fr << 40), stream);
+    }
+    int in_group = 0;  // the group the next step reads
     hipEvent_t done[2], sent[2];
     for (int b = 0; b < 2; b++) {
       CHECK_HIP(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
@@ -172,8 +200,10 @@ int main(int argc, char** argv) {
     const std::vector<P2POp> ops = gather ? gather_ops(w, out_bytes_of) : std::vector<P2POp>();
     auto transform = [&](uint8_t* out) {
       if (nf == 0) return;
-      const int ok = depth > 0 ? T360_transformFramesPipelined(t, d_in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3)
-                               : T360_transformFrames(t, d_in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3);
+      const uint8_t* in = d_in + (size_t)in_group * step_in;
+      in_group = in_group + 1 == groups ? 0 : in_group + 1;
+      const int ok = depth > 0 ? T360_transformFramesPipelined(t, in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3)
+                               : T360_transformFrames(t, in, lin.frame_bytes, out, lout.frame_bytes, nf, planes, 3);
       if (!ok) exit(1);
     };
     auto step = [&](int k) {
@@ -208,13 +238,20 @@ int main(int argc, char** argv) {
     for (int k = 0; k < kWarmSteps; k++) step(k);
     if (!T360_synchronize(t)) exit(1);
     CHECK_HIP(hipStreamSynchronize(side));
+    gate();
     const auto t0 = std::chrono::steady_clock::now();
+    if (w == 0) t_start = t0;
     for (int k = 0; k < steps; k++) step(k);
     if (!T360_synchronize(t)) exit(1);  // the handle's stream and, with --pipelined, every lane
     CHECK_HIP(hipStreamSynchronize(side));
     ms[(size_t)w] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    gate();
+    if (w == 0) t_end = std::chrono::steady_clock::now();
+    // the checksum is of the stream's own frames (group 0): one more plain step, outside the timed region
+    in_group = 0;
+    if (nf > 0 && (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[0], lout.frame_bytes, nf, planes, 3) || !T360_synchronize(t))) exit(1);
     std::vector<uint8_t> host((size_t)nf * lout.frame_bytes);
-    if (nf > 0) CHECK_HIP(hipMemcpy(host.data(), d_out[(size_t)(gather ? buffer_of_step(steps - 1) : (steps - 1) % nbuf)], host.size(), hipMemcpyDeviceToHost));
+    if (nf > 0) CHECK_HIP(hipMemcpy(host.data(), d_out[0], host.size(), hipMemcpyDeviceToHost));
     unsigned long long s = 0;
     for (uint8_t v : host) s += v;
     sums[(size_t)w] = s;
@@ -226,12 +263,12 @@ int main(int argc, char** argv) {
   std::vector<std::thread> th;
   for (int w = 0; w < workers; w++) th.emplace_back(worker, w);
   for (auto& x : th) x.join();
-  double worst = 0;
+  // the job's time: from the moment all workers are released to the moment the last one is done
+  double worst = std::chrono::duration<double, std::milli>(t_end - t_start).count();
   int frames_per_step = 0;
   for (int w = 0; w < workers; w++) {
     printf("device %d (worker %d): %.4f ms per step of %d frames [%d, %d), output checksum %llu\n", device_of[(size_t)w], w,
            ms[(size_t)w] / steps, hi[(size_t)w] - lo[(size_t)w], lo[(size_t)w], hi[(size_t)w], sums[(size_t)w]);
-    worst = ms[(size_t)w] > worst ? ms[(size_t)w] : worst;
     frames_per_step += hi[(size_t)w] - lo[(size_t)w];
   }
   printf("%d worker(s) on %d device(s), %s scaling, %s%s: %.1f Mpix/s (%.0f frames/s), %.4f ms per step of %d frames\n", workers, ndev,

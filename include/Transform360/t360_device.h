@@ -77,6 +77,14 @@ int T360_transformFramesPipelined(VideoFrameTransform* transform,
                                   const uint8_t* d_in, int64_t in_frame_bytes,
                                   uint8_t* d_out, int64_t out_frame_bytes,
                                   int n_frames, const T360PlaneDesc* planes, int n_planes);
+/* n_calls pipelined calls issued back to back from native code: call k reads d_in[k] and writes d_out[k] (same frame
+ * sizes, frame count and planes for all).  Exactly equivalent to the loop
+ *     for (k = 0; k < n_calls; k++) T360_transformFramesPipelined(t, d_in[k], ..., d_out[k], ...);
+ * for callers whose own loop is slow next to a 35-us step (an interpreter: bench.py).  Stops at the first failure. */
+int T360_transformFramesPipelinedMany(VideoFrameTransform* transform, int n_calls,
+                                      const uint8_t* const* d_in, int64_t in_frame_bytes,
+                                      uint8_t* const* d_out, int64_t out_frame_bytes,
+                                      int n_frames, const T360PlaneDesc* planes, int n_planes);
 int T360_setPipelineDepth(VideoFrameTransform* transform, int depth);
 int T360_pipelineJoin(VideoFrameTransform* transform);
 

@@ -270,7 +270,10 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
     const int q = total >> 3, rem = total & 7;
     const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
     L2 l2(l2_bytes, ways);
-    struct Slot { int tile = -1, f = 0, f1 = 0, wait = 0, rot = 0, done = 0; };
+    struct Slot { int tile = -1, f = 0, f1 = 0, wait = 0, rot = 0, done = 0; long long myF = -1; unsigned long long mask = 0; };
+    // lead <= -2 (round 5, follow-the-frontier): the XCD's 'newest frame started' word (frame = counter mod run length);
+    // lead == -4: the frontier is the AVERAGE progress instead (steps taken on the XCD / resident workgroups)
+    long long frontier = 0, votes = 0;
     int front = 0;
     const double startup = 5.0;
     std::vector<Slot> slot((size_t)slots);
@@ -312,10 +315,11 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
         speed[(size_t)si] = 1.0 + 0.01 * spread * uni(rng);
         tnext[(size_t)si] += startup;  // start-up
         s.rot = 0;
-        if (lead < 0) {  // start at the frame the XCD's front is on (+ what it will advance during my start-up), wrap around
+        if (lead == -1) {  // start at the frame the XCD's front is on (+ what it will advance during my start-up), wrap around
           s.rot = (front + (int)(startup / 1.0)) % (s.f1 - s.f);
         }
         s.done = 0;
+        s.myF = -1; s.mask = 0;
         continue;
       }
       if (lead >= 100) {
@@ -336,8 +340,29 @@ extern "C" long long t360_l2sim(const t360::LutEntry* lut_y, int dwy, int dhy, i
       }
       const SimTile& t = tiles[(size_t)s.tile];
       const int nfr = s.f1 - (s.f - s.done);
-      const int fr = (s.f - s.done) + (s.rot + s.done) % nfr;
-      if (lead < 0) front = fr;
+      int fr = (s.f - s.done) + (s.rot + s.done) % nfr;
+      if (lead == -1) front = fr;
+      if (lead <= -2) {
+        // follow the frontier without waiting: propose my last frontier value + 1, take the maximum anyone has proposed
+        // (one L2-local atomic max per step); if I have done that frame already, fill a hole (-2: the next undone frame
+        // after it, cyclically; -3: my lowest undone one).  -4: the frontier is the XCD's average progress.
+        long long cur;
+        if (lead == -4) {
+          votes++;
+          cur = votes / slots;
+        } else {
+          cur = std::max(frontier, s.myF + 1);
+          frontier = cur;
+        }
+        s.myF = cur;
+        int r = (int)(cur % nfr);
+        if ((s.mask >> r) & 1ull) {
+          if (lead != -3) { while ((s.mask >> r) & 1ull) r = r + 1 == nfr ? 0 : r + 1; }
+          else { r = 0; while ((s.mask >> r) & 1ull) r++; }
+        }
+        s.mask |= 1ull << r;
+        fr = (s.f - s.done) + r;
+      }
       const long long pbase = (long long)fr * frame_in + (t.plane == 0 ? 0 : t.plane == 1 ? ybytes : ybytes + cbytes);
       const int stride = t.plane ? swc : swy;
       long long prev_nt = -1;

@@ -307,6 +307,13 @@ def test_pipelined_calls_equal_plain_calls_and_the_oracle(ov, depth, T, oracle_m
         torch.cuda.synchronize()
         for b in range(nb):
             assert torch.equal(got[b], want[b]), "pipelined batch %d differs from the plain call" % b
+        # the same seven calls issued by the library's own loop (T360_transformFramesPipelinedMany), one buffer per call
+        many = [torch.zeros(n * lout.frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()
+        assert t.transformFramesPipelinedMany(batches, lin.frame_bytes, many, lout.frame_bytes, n, descs)
+        assert t.synchronize()
+        for b in range(nb):
+            assert torch.equal(many[b], want[b]), "batch %d of the bulk call differs from the plain call" % b
     o = O.Oracle(ctx, threads=4)
     for idx, k in ((0, 0), (1, 1)):
         assert o.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)

@@ -121,6 +121,17 @@ T360_EXPORT int T360_transformFramesPipelined(VideoFrameTransform* t, const uint
   });
 }
 
+T360_EXPORT int T360_transformFramesPipelinedMany(VideoFrameTransform* t, int n_calls, const uint8_t* const* d_in,
+                                                  int64_t in_frame_bytes, uint8_t* const* d_out, int64_t out_frame_bytes,
+                                                  int n_frames, const T360PlaneDesc* planes, int n_planes) {
+  if (!t || n_calls < 0 || (n_calls > 0 && (!d_in || !d_out))) return 0;
+  return guarded("T360_transformFramesPipelinedMany", [&] {
+    for (int k = 0; k < n_calls; k++)
+      if (!t->transformFramesPipelined(d_in[k], in_frame_bytes, d_out[k], out_frame_bytes, n_frames, planes, n_planes)) return false;
+    return true;
+  });
+}
+
 T360_EXPORT int T360_setPipelineDepth(VideoFrameTransform* t, int depth) {
   if (!t) return 0;
   return guarded("T360_setPipelineDepth", [&] { return t->setPipelineDepth(depth); });

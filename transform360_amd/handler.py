@@ -135,6 +135,17 @@ class VideoFrameTransform:
             self._h, d_in.data_ptr(), in_frame_bytes, d_out.data_ptr(), out_frame_bytes, n_frames,
             descs, len(descs)))
 
+    def transformFramesPipelinedMany(self, d_ins, in_frame_bytes, d_outs, out_frame_bytes, n_frames, descs):
+        """len(d_ins) pipelined calls issued by one native loop (T360_transformFramesPipelinedMany); d_ins / d_outs are lists
+        of tensors or raw device addresses."""
+        n = len(d_ins)
+        assert n == len(d_outs)
+        ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else int(x)
+        ins = (C.c_void_p * n)(*[ptr(x) for x in d_ins])
+        outs = (C.c_void_p * n)(*[ptr(x) for x in d_outs])
+        return bool(self._l.T360_transformFramesPipelinedMany(self._h, n, ins, in_frame_bytes, outs, out_frame_bytes, n_frames,
+                                                              descs, len(descs)))
+
     def setPipelineDepth(self, depth):
         return bool(self._l.T360_setPipelineDepth(self._h, depth))
 
