@@ -26,6 +26,7 @@ CASES = {
     "eac_tb": (dict(interpolation_alg=CUBIC, output_layout=LAYOUT_EAC_32, input_stereo_format=STEREO_FORMAT_TB,
                     output_stereo_format=STEREO_FORMAT_TB), (512, 512, 288, 384)),
     "ragged_output": (dict(interpolation_alg=CUBIC), (640, 320, 300, 200)),
+    "config1_luma": (dict(interpolation_alg=NEAREST), (1920, 960, 768, 512)),      # BASELINE config 1
     "config2_luma": (dict(interpolation_alg=CUBIC), (3840, 1920, 1536, 1024)),     # BASELINE config 2, both plane shapes
     "config2_chroma": (dict(interpolation_alg=CUBIC), (1920, 960, 768, 512)),
 }
@@ -41,7 +42,8 @@ def sim():
 
 
 @pytest.mark.parametrize("waves,pieces", [(8, 24), (4, 16), (8 | (1000 << 8) | (1 << 20), 24),   # the third: 256x8 tiles wherever they fit
-                                          (8 | (4 << 24), 24), (8 | (2 << 24), 24)])                # scatter tiles, strips of 4 / 2 lines
+                                          (8 | (4 << 24), 24), (8 | (2 << 24), 24),                 # scatter tiles, strips of 4 / 2 lines
+                                          (4 | (1 << 20), 12)])   # shapes compared by lines on 4 waves: what nearest maps run with
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gather_through_the_plan_reads_the_right_bytes(name, waves, pieces, sim, oracle_mod):
     O = oracle_mod

@@ -483,7 +483,9 @@ class Planner {
   // (infeasible 16x16 tiles -- the direct tiles around the poles -- count as their pixels' stencils read one by one)
   int64_t choose_region(int ox, int oy, std::vector<Foot>* pick) const {
     const bool only16 = opt_.ks == 8;  // Lanczos4 keeps 32 weight dwords per pixel in registers: one pixel per lane
-    const bool wide_ok = !only16 && opt_.wide_pct > 0 && opt_.ks != 1;  // nearest has no halo to share
+    // (nearest has no stencil halo to share: by staged chunks a wider tile never wins -- by the 128-byte LINES under its
+    // longer row fragments it does, so nearest maps take wide tiles only when shapes are compared by lines)
+    const bool wide_ok = !only16 && opt_.wide_pct > 0 && (opt_.ks != 1 || opt_.cost_lines);
     const bool strip_ok = !only16 && opt_.strip_pct > 0;
     Foot strip[4], wide[2], sq[4], small;
     // squares first (always evaluated: they are the fallback), then the wider shapes

@@ -1328,7 +1328,11 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small, std::vecto
   o.strip_pct = plan_strip_pct_;
   o.wide256_pct = small ? 0 : plan_wide256_pct_;
   o.scatter = small ? 0 : plan_scatter_;
-  o.cost_lines = plan_cost_lines_ != 0;
+  // nearest-neighbour maps: a pixel has no stencil halo, so by staged chunks a 32x32 tile always looked as good as a 64x16
+  // one -- but its 77-byte row fragments touch 1.6 lines for every 0.6 they need.  Compared by the 128-byte lines under
+  // their fragments the planner takes 64x16 tiles: BASELINE config 1, 64 frames 0.0639 -> 0.0579 ms on the same box
+  // (tools/experiments_r05/call8.sh)
+  o.cost_lines = plan_cost_lines_ != 0 || ks == 1;
   o.band = plan_band_ > 0 ? plan_band_ : 4;
   o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
   o.row_pad = plan_row_pad_;
