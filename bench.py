@@ -750,10 +750,11 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 w8 += 16
             warm_steps(8, max(2, args.warmup))
             e8 = sorted(r[0] for r in timed_run(8, args.steps, False, rotate=rotate))[REPEATS // 2]
+            t64 = elapsed  # the headline's own K steps of 64 frames (what `value` and `ms_per_step` are computed from)
             strong["projected_8_gpus"] = {
                 "frames_per_gpu": 8, "ms_per_step": round(e8 / args.steps * 1e3, 4),
-                "speedup_over_1_gpu": round(s_el / e8, 2),
-                "what": "one GPU's share at 8 GPUs (8 frames per step) timed on this GPU; speedup = this line's 64-frame step time / "
+                "speedup_over_1_gpu": round(t64 / e8, 2),
+                "what": "one GPU's share at 8 GPUs (8 frames per step) timed on this GPU; speedup = this line's `ms_per_step` (64 frames) / "
                         "the 8-frame step time (no inter-GPU traffic on the path: frames are sharded, SURVEY 8e)"}
             if not args.no_two_streams:
                 for k in range(2 * args.pipeline_depth):
@@ -764,11 +765,11 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                 p8 = strong["projected_8_gpus"]
                 p8["one_stream_ms_per_step"], p8["one_stream_speedup_over_1_gpu"] = p8["ms_per_step"], p8["speedup_over_1_gpu"]
                 p8["ms_per_step"] = round(e8p / args.steps * 1e3, 4)
-                p8["speedup_over_1_gpu"] = round(s_el / e8p, 2)
+                p8["speedup_over_1_gpu"] = round(t64 / e8p, 2)
                 p8["what"] = ("one GPU's share at 8 GPUs (8 frames per step, input rotating through HBM) timed on this GPU the way a GPU of "
                               "the node would be driven: a stream of 8-frame steps through T360_transformFramesPipelined (one handle, "
                               "%d internal streams; the K calls issued by T360_transformFramesPipelinedMany).  speedup = this line's "
-                              "one-stream 64-frame step time / that 8-frame step time; one_stream_* = the same steps as plain "
+                              "`ms_per_step` (64 frames, one stream) / that 8-frame step time; one_stream_* = the same steps as plain "
                               "T360_transformFrames calls back to back.  No inter-GPU traffic on the path: frames are sharded "
                               "(SURVEY 8e)" % args.pipeline_depth)
                 if pipelined_64 is not None:

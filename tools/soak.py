@@ -37,6 +37,23 @@ for i in range(iters):
     if not torch.equal(out, ref):
         bad += 1
         print("iteration %d differs in %d bytes" % (i, int((out != ref).sum().item())))
-print("config %d: %d iterations x %d frames, %d differing" % (cfg, iters, F, bad))
+# the same batch through the pipelined calls (T360_transformFramesPipelined, three lanes, three output buffers): overlapping
+# launches on different streams must not disturb each other either
+assert t.setPipelineDepth(3)
+outs = [torch.zeros_like(ref) for _ in range(3)]
+pbad = 0
+piters = max(3, iters // 3)
+for i in range(piters):
+    assert t.transformFramesPipelined(d_in, lin.frame_bytes, outs[i % 3], lout.frame_bytes, F, descs)
+    if i % 3 == 2:
+        assert t.synchronize()
+        for o in outs:
+            if not torch.equal(o, ref):
+                pbad += 1
+            o.zero_()
+        torch.cuda.synchronize()
+assert t.synchronize()
+bad += pbad
+print("config %d: %d iterations x %d frames, %d differing (of which pipelined calls: %d iterations, %d differing)" % (cfg, iters, F, bad, piters, pbad))
 t.close()
 sys.exit(1 if bad else 0)
