@@ -293,6 +293,46 @@ def host_abi_rate(wl, lin, lout, ctx):
             "note": "host pointers, 3 synchronous calls per frame (the ffmpeg filter's pattern); PCIe-inclusive, not `value`"}
 
 
+def native_driver_leg(world):
+    """The same steps driven by the repo's own C++ host (examples/t360_multi_gpu.cpp: ONE process, one thread + handle + stream
+    per device, no Python anywhere near the loop): weak scaling (64 frames per device and step) and BASELINE configs[4] as
+    written (64 frames per step sharded over the devices, pipelined calls).  Compute only -- no RCCL is initialised, the
+    devices are used exactly as the ranks of this script use them.  Run by rank 0 after every rank's timed legs are over."""
+    import re
+    exe = os.path.join(ROOT, "examples", "t360_multi_gpu")
+    if not os.path.exists(exe):
+        return {"skipped": "examples/t360_multi_gpu is not built (make -C examples; __graft_entry__.build() does it)"}
+    out_mpix = 1.572864
+    import torch
+    ndev = max(1, min(world, torch.cuda.device_count()))  # (a gloo rehearsal has more ranks than devices: workers then share)
+
+    def run(label, extra, steps):
+        cmd = [exe, "--devices", str(ndev), "--workers", str(world), "--ring-mb", "1440", "--steps", str(steps)] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout", "cmd": " ".join(cmd[1:])}
+        m = re.search(r"\(([0-9.]+) frames/s\), ([0-9.]+) ms per step of (\d+) frames", r.stdout)
+        if r.returncode != 0 or not m:
+            return {"error": (r.stdout + r.stderr)[-300:], "cmd": " ".join(cmd[1:])}
+        fps, ms, frames = float(m.group(1)), float(m.group(2)), int(m.group(3))
+        return {"what": label, "cmd": "examples/t360_multi_gpu " + " ".join(cmd[1:]), "ms_per_step": ms, "frames_per_step": frames,
+                "value": round(fps * out_mpix, 1), "unit": "Mpix/s"}
+
+    rec = {"host": "C++ (examples/t360_multi_gpu.cpp), one process, one thread + handle + stream per device, compute only",
+           "n_devices": ndev, "workers": world,
+           "weak_64_frames_per_device": run("64 frames per device and step, plain calls, input rotating through HBM", ["--frames", "64"], 100),
+           "strong_cfg5_64_frames_total": run("BASELINE configs[4]: 64 frames per step sharded over the devices, pipelined calls (depth 2)",
+                                              ["--total-frames", "64", "--pipelined", "2"], 200 if world > 1 else 100)}
+    if world == 1:
+        rec["one_gpu_share_of_8"] = run("8 frames per step (one GPU's share at 8 GPUs), pipelined calls (depth 2)",
+                                        ["--frames", "8", "--pipelined", "2"], 400)
+        a, b = rec["weak_64_frames_per_device"], rec["one_gpu_share_of_8"]
+        if "ms_per_step" in a and "ms_per_step" in b:
+            rec["projected_speedup_at_8_gpus"] = round(a["ms_per_step"] / b["ms_per_step"], 2)
+    return rec
+
+
 def self_launch(args):
     """--gpus N without a launcher: start the N ranks ourselves."""
     with socket.socket() as s:
@@ -1008,6 +1048,7 @@ def main():
                     help="skip the legs that issue steps through T360_transformFramesPipelined (kernel traces: overlapped "
                          "launches of the hot kernel would enter its average duration)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="internal streams of the pipelined legs (1..4)")
+    ap.add_argument("--no-native", action="store_true", help="skip the leg that runs the native C++ driver (examples/t360_multi_gpu)")
     ap.add_argument("--two-handles", action="store_true", help="also time steps alternating between two handles on two streams (development)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
@@ -1065,7 +1106,29 @@ def main():
     ctx = filter_defaults(**wl["ov"])
     res, path, (lin, lout) = run_rank(args, StubPath if args.stub else HipPath, dist, rank, world, coll_dev, wl, ctx)
 
+    # The repo's own C++ host on the same devices (north_star: "host side is the repo's own C++"): after every rank is done,
+    # rank 0 runs the native driver over all `world` devices while the other ranks wait on the rendezvous store (a CPU-side
+    # wait: an RCCL barrier would park a spinning kernel on every other GPU).
+    native = None
+    if not args.stub and args.config == 2 and not args.no_native and not build_flags:
+        path.sync()
+        store = None
+        if dist is not None:
+            dist.barrier()
+            path.sync()
+            store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                native = native_driver_leg(world)
+            except Exception as e:  # the benchmark line never depends on the example binary
+                native = {"error": repr(e)[:300]}
+            if store is not None:
+                store.set("t360_native_done", "1")
+        elif store is not None:
+            store.wait(["t360_native_done"])
     if rank == 0:
+        if native is not None:
+            res["native_driver"] = native
         if not args.stub:
             res["library"] = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "build_flags": build_flags,
                               "version": _lib.load().T360_version().decode()}

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() { # name counters...
   local name=$1; shift
   timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
-      python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-host-abi --no-two-streams "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
+      python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-host-abi --no-two-streams --no-native "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1 || echo "pass $name failed"
 }
 BENCH_ARGS=("$@")
 if [ "${PMC_MEM:-0}" != "only" ]; then

@@ -20,12 +20,12 @@ grep -h "^{\"metric\"" "$OUT/bench_8frames.log" | tail -1 > "$R/profiles/${TAG}_
 for CFG in 2 1 3 4; do
   SUF=$([ $CFG = 2 ] && echo "" || echo "_cfg$CFG")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace$CFG" -o "$TAG" -- \
-      python "$R/bench.py" --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-host-abi --no-two-streams > "$OUT/trace$CFG.log" 2>&1
+      python "$R/bench.py" --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-host-abi --no-two-streams --no-native > "$OUT/trace$CFG.log" 2>&1
   cp "$OUT/trace$CFG/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}${SUF}_kernel_stats.csv" 2>/dev/null
   grep -h "^{\"metric\"" "$OUT/trace$CFG.log" | tail -1 > "$R/profiles/${TAG}${SUF}_bench_under_rocprof.json"
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace8" -o "$TAG" -- \
-    python "$R/bench.py" --frames 8 --steps 20 --warmup 3 --no-cpu-baseline --no-host-abi --no-verify --no-two-streams > "$OUT/trace8.log" 2>&1
+    python "$R/bench.py" --frames 8 --steps 20 --warmup 3 --no-cpu-baseline --no-host-abi --no-verify --no-two-streams --no-native > "$OUT/trace8.log" 2>&1
 cp "$OUT/trace8/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_8frames_kernel_stats.csv" 2>/dev/null
 cd "$R" && PMC_MEM=1 tools/prof_pmc.sh "$OUT/pmc" --no-verify > /dev/null 2>&1
 cp "$OUT/pmc/summary.txt" "$R/profiles/${TAG}_pmc_summary.txt"
