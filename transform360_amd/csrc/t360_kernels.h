@@ -112,6 +112,14 @@ struct LowpassArgs {
   const uint32_t* taps_sh;    // SegmentDev::kxs_off
 };
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream);
+// the wide fast path of up to three planes (the Y, U and V of a batch) as ONE launch; only when every plane is served by
+// wide tiles alone with the same vertical tap count (lowpass_mergeable)
+struct LowpassMulti {
+  LowpassArgs p[3];
+  int n;
+};
+bool lowpass_mergeable(const LowpassArgs* a, int n);
+hipError_t launch_lowpass_multi(const LowpassArgs* a, int n, int nframes, hipStream_t stream);
 
 // ---- INTER_AREA shrink of the supersampled plane (t360_resize.hip) ----
 struct ResizeArgs {

@@ -442,15 +442,9 @@ __device__ __forceinline__ void lowpass_q8w_tile(const LowpassArgs& a, const Low
   lowpass_q8w_rows<KY, ND, KX>(a, t, box + lead, pitch, kxs, kyv, dst);
 }
 
+// one wide tile `ti` of plane `a`, frame blockIdx.y
 template <int KY>
-__global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int lds_rows[];
-  uint32_t* __restrict__ box = reinterpret_cast<uint32_t*>(lds_rows);
-
-  // XCD x (= id % 8) walks the x-th eighth of the row-major tile list
-  const int per = (a.nwide + 7) >> 3;
-  const int xcd = blockIdx.x & 7, ti = xcd * per + (int)(blockIdx.x >> 3);
-  if (ti >= min((xcd + 1) * per, a.nwide)) return;
+__device__ __forceinline__ void lowpass_q8w_item(const LowpassArgs& a, int ti, uint32_t* __restrict__ box) {
   const LowpassTile t = a.wide_tiles[ti];
   const SegmentDev s = a.segs[t.seg];
   const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.y * a.src_frame_bytes;
@@ -474,7 +468,71 @@ __global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
   }
 }
 
+template <int KY>
+__global__ __launch_bounds__(256) void lowpass_q8w_kernel(LowpassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_rows[];
+  // XCD x (= id % 8) walks the x-th eighth of the row-major tile list
+  const int per = (a.nwide + 7) >> 3;
+  const int xcd = blockIdx.x & 7, ti = xcd * per + (int)(blockIdx.x >> 3);
+  if (ti >= min((xcd + 1) * per, a.nwide)) return;
+  lowpass_q8w_item<KY>(a, ti, reinterpret_cast<uint32_t*>(lds_rows));
+}
+
+// The planes of a batch (Y, U, V) in ONE launch: the merged tile list is plane 0's row-major list, then plane 1's, then
+// plane 2's, and XCD x walks the x-th eighth of it.  (Round 5: three launches on three streams overlap as well, but each
+// ramps up and drains on its own and the step pays two event joins; reference filterPlane is called once per plane,
+// VideoFrameTransform.cpp:727-733 -- the planes are independent.)
+template <int KY>
+__global__ __launch_bounds__(256) void lowpass_q8w_multi_kernel(LowpassMulti m) {
+  extern __shared__ __attribute__((aligned(16))) int lds_rows[];
+  const int total = m.p[0].nwide + (m.n > 1 ? m.p[1].nwide : 0) + (m.n > 2 ? m.p[2].nwide : 0);
+  const int per = (total + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  int ti = xcd * per + (int)(blockIdx.x >> 3);
+  if (ti >= min((xcd + 1) * per, total)) return;
+  // pick the plane with scalar selects (indexing m.p[] with a run-time index would copy the argument block to scratch)
+  LowpassArgs a = m.p[0];
+  if (m.n > 1 && ti >= a.nwide) {
+    ti -= a.nwide;
+    a = m.p[1];
+    if (m.n > 2 && ti >= a.nwide) {
+      ti -= a.nwide;
+      a = m.p[2];
+    }
+  }
+  lowpass_q8w_item<KY>(a, ti, reinterpret_cast<uint32_t*>(lds_rows));
+}
+
 }  // namespace
+
+bool lowpass_mergeable(const LowpassArgs* a, int n) {
+  if (n < 2 || n > 3) return false;
+  for (int k = 0; k < n; k++)
+    if (a[k].nwide <= 0 || a[k].nfast > 0 || a[k].ntiles > 0 || a[k].fast_ky != a[0].fast_ky) return false;
+  return a[0].fast_ky == 3 || a[0].fast_ky == 5 || a[0].fast_ky == 7;
+}
+
+hipError_t launch_lowpass_multi(const LowpassArgs* a, int n, int nframes, hipStream_t stream) {
+  if (nframes <= 0) return hipSuccess;
+  if (!lowpass_mergeable(a, n)) return hipErrorInvalidValue;
+  LowpassMulti m;
+  m.n = n;
+  int total = 0, lds = 0;
+  for (int k = 0; k < 3; k++) {
+    m.p[k] = a[k < n ? k : 0];
+    if (k < n) {
+      total += a[k].nwide;
+      lds = a[k].wide_lds_bytes > lds ? a[k].wide_lds_bytes : lds;
+    }
+  }
+  const dim3 grid(8 * ((total + 7) / 8), nframes, 1);
+  switch (a[0].fast_ky) {
+    case 3: hipLaunchKernelGGL(lowpass_q8w_multi_kernel<3>, grid, dim3(256), (size_t)lds, stream, m); break;
+    case 5: hipLaunchKernelGGL(lowpass_q8w_multi_kernel<5>, grid, dim3(256), (size_t)lds, stream, m); break;
+    default: hipLaunchKernelGGL(lowpass_q8w_multi_kernel<7>, grid, dim3(256), (size_t)lds, stream, m); break;
+  }
+  return hipGetLastError();
+}
 
 hipError_t launch_lowpass(const LowpassArgs& a, int nframes, hipStream_t stream) {
   if (nframes <= 0) return hipSuccess;

@@ -207,6 +207,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (getenv("T360_NO_TILED")) use_tiled_ = false;
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
   if (getenv("T360_NO_WIDE_LOWPASS")) use_wide_lowpass_ = false;
+  if (getenv("T360_NO_MERGED_LOWPASS")) merge_lowpass_ = false;
 #endif
   ok_ = true;
 }
@@ -887,18 +888,10 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
   return true;
 }
 
-bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes,
-                                     int in_stride, uint8_t* d_out, int64_t out_frame_bytes,
-                                     int out_stride, int w, int h, int n_frames, int imagePlaneIndex,
-                                     hipStream_t stream) {
-  if (!ensureTiles(p, w, h, imagePlaneIndex)) return false;
-  if (!p.full_cover) {
-    // Mat::zeros(...) of filterPlane (:625): only visible where no segment writes
-    for (int f = 0; f < n_frames; f++)
-      if (!check(hipMemset2DAsync(d_out + (size_t)f * out_frame_bytes, (size_t)out_stride, 0, (size_t)w,
-                                  (size_t)h, stream), "hipMemset2DAsync"))
-        return false;
-  }
+// launch arguments of the low-pass of one plane (after ensureTiles)
+void VideoFrameTransform::fillLowpassArgs(const PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
+                                          uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h,
+                                          t360::LowpassArgs* out) const {
   LowpassArgs a;
   a.src = d_in;
   a.src_frame_bytes = in_frame_bytes;
@@ -940,6 +933,23 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
     a.ntiles = p.ntiles;
     a.max_rows = p.max_rows;
   }
+  *out = a;
+}
+
+bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes,
+                                     int in_stride, uint8_t* d_out, int64_t out_frame_bytes,
+                                     int out_stride, int w, int h, int n_frames, int imagePlaneIndex,
+                                     hipStream_t stream) {
+  if (!ensureTiles(p, w, h, imagePlaneIndex)) return false;
+  if (!p.full_cover) {
+    // Mat::zeros(...) of filterPlane (:625): only visible where no segment writes
+    for (int f = 0; f < n_frames; f++)
+      if (!check(hipMemset2DAsync(d_out + (size_t)f * out_frame_bytes, (size_t)out_stride, 0, (size_t)w,
+                                  (size_t)h, stream), "hipMemset2DAsync"))
+        return false;
+  }
+  LowpassArgs a;
+  fillLowpassArgs(p, d_in, in_frame_bytes, in_stride, d_out, out_frame_bytes, out_stride, w, h, &a);
   return check(launch_lowpass(a, n_frames, stream), "low-pass launch");
 }
 
@@ -1084,9 +1094,36 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       total += (size_t)bstride * jobs[k].in_h * (size_t)n_frames;
     }
     if (!blurred_[scratch_].reserve(total)) return check(hipErrorOutOfMemory, "hipMalloc(blurred)");
+    // The planes of a yuv420p batch as ONE launch when every plane is served by the wide fixed-point tiles alone (BASELINE
+    // config 3 is): one ramp and one drain instead of three, no event joins.  Anything else -- float-path segments, odd
+    // widths, a plane its segments do not cover, one map named with two sizes -- takes the per-plane launches below.
+    bool merged = false;
+    if (njobs >= 2 && njobs <= 3 && use_wide_lowpass_ && merge_lowpass_) {
+      LowpassArgs la[3];
+      bool ok = true;
+      for (int k = 0; k < njobs && ok; k++) {
+        const PlaneJob& j = jobs[k];
+        PlaneState& pk = planes_[j.idx];
+        for (int m = 0; m < k; m++) ok = ok && !(jobs[m].idx == j.idx && (jobs[m].in_w != j.in_w || jobs[m].in_h != j.in_h));
+        if (!ok) break;
+        if (!ensureTiles(pk, j.in_w, j.in_h, j.image_plane)) return false;
+        const int bstride = (j.in_w + 255) & ~255;
+        fillLowpassArgs(pk, j.in, j.in_frame_bytes, j.in_stride, blurred_[scratch_].as<uint8_t>() + offs[(size_t)k],
+                        (int64_t)bstride * j.in_h, bstride, j.in_w, j.in_h, &la[k]);
+        ok = pk.full_cover;
+      }
+      if (ok && lowpass_mergeable(la, njobs)) {
+        if (!check(launch_lowpass_multi(la, njobs, n_frames, stream_), "low-pass launch")) return false;
+        for (int k = 0; k < njobs; k++) {
+          const int bstride = (jobs[k].in_w + 255) & ~255;
+          srcs[(size_t)k] = Src{blurred_[scratch_].as<uint8_t>() + offs[(size_t)k], (int64_t)bstride * jobs[k].in_h, bstride};
+        }
+        merged = true;
+      }
+    }
     const bool side = njobs > 1 && njobs <= 4;  // planes 1.. on their own streams beside plane 0
-    if (side && !check(hipEventRecord(lp_fork_, stream_), "hipEventRecord")) return false;
-    for (int k = 0; k < njobs; k++) {
+    if (side && !merged && !check(hipEventRecord(lp_fork_, stream_), "hipEventRecord")) return false;
+    for (int k = 0; k < njobs && !merged; k++) {
       const PlaneJob& j = jobs[k];
       const int bstride = (j.in_w + 255) & ~255;
       const int64_t plane_bytes = (int64_t)bstride * j.in_h;

@@ -126,6 +126,8 @@ class VideoFrameTransform {
   bool runPlanes(const PlaneJob* jobs, int njobs, int n_frames);
   bool runPlanesScaled(const PlaneJob* jobs, int njobs, int n_frames);
   bool buildResizePlan(PlaneState& p, int dw, int dh);
+  void fillLowpassArgs(const PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride, uint8_t* d_out,
+                       int64_t out_frame_bytes, int out_stride, int w, int h, t360::LowpassArgs* out) const;
   bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
                   int imagePlaneIndex, hipStream_t stream);
@@ -164,6 +166,7 @@ class VideoFrameTransform {
   char last_kernel_[64] = "";  // gather kernel of the most recent launch (reporting); the buffer lives as long as the handle
   void setLastKernel(const char* name) { snprintf(last_kernel_, sizeof(last_kernel_), "%s", name); }
   bool use_fast_lowpass_ = true;
+  bool merge_lowpass_ = true;     // Y, U and V of a batch in one launch where the wide tiles serve all of them (T360_NO_MERGED_LOWPASS)
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
   // scratch planes: [0] for the calls on the handle's stream, [1 + lane] for the pipelined calls of that lane (calls on
   // different lanes overlap on the device and must not share intermediates)
