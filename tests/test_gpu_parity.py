@@ -328,6 +328,47 @@ def test_pipelined_calls_equal_plain_calls_and_the_oracle(ov, depth, T, oracle_m
     o.close()
 
 
+def test_pipelined_calls_that_name_a_map_with_two_plane_sizes(T):
+    """Consecutive pipelined calls that name map 0 with two plane sizes (the filter's alpha-plane quirk as a stream): the
+    per-map low-pass tile lists and INTER_AREA tables are rebuilt in place for every call, so the library must not start
+    rewriting them while the previous call still runs on another lane.  Every output equals the plain call's."""
+    import torch
+    from transform360_amd import _lib
+    ctx = filter_defaults(num_vertical_segments=5, num_horizontal_segments=4)
+    n = 4
+    lin, lout = T.FrameLayout(480, 240, planes=1), T.FrameLayout(192, 128, planes=1)
+    lin2, lout2 = T.FrameLayout(240, 120, planes=1), T.FrameLayout(96, 64, planes=1)
+
+    def desc(a, b):
+        d = (_lib.T360PlaneDesc * 1)()
+        d[0] = _lib.T360PlaneDesc(in_offset=0, out_offset=0, in_stride=a.strides[0], out_stride=b.strides[0], in_width=a.dims[0][0],
+                                  in_height=a.dims[0][1], out_width=b.dims[0][0], out_height=b.dims[0][1], map_index=0)
+        return d
+    shapes = [(lin, lout, desc(lin, lout)), (lin2, lout2, desc(lin2, lout2))]
+    with T.VideoFrameTransform(ctx) as t:
+        assert t.generateMapForPlane(480, 240, 192, 128, 0)
+        ins, want = [], []
+        for b in range(6):
+            a, o_, d = shapes[b & 1]
+            x = torch.empty(n * a.frame_bytes, dtype=torch.uint8, device="cuda")
+            for k in range(n):
+                T.fill_noise(x[k * a.frame_bytes:(k + 1) * a.frame_bytes], T.frame_seed(900 + 10 * b + k))
+            y = torch.zeros(n * o_.frame_bytes, dtype=torch.uint8, device="cuda")
+            _ready()
+            assert t.transformFrames(x, a.frame_bytes, y, o_.frame_bytes, n, d) and t.synchronize()
+            ins.append(x)
+            want.append(y)
+        assert t.setPipelineDepth(3)
+        got = [torch.zeros_like(w) for w in want]
+        _ready()
+        for b in range(6):
+            a, o_, d = shapes[b & 1]
+            assert t.transformFramesPipelined(ins[b], a.frame_bytes, got[b], o_.frame_bytes, n, d)
+        assert t.synchronize()
+        for b in range(6):
+            assert torch.equal(got[b], want[b]), "pipelined call %d differs" % b
+
+
 @pytest.mark.parametrize("interp", [NEAREST, LINEAR, LANCZOS4])
 def test_batch_other_interpolations_tiled(interp, T, oracle_mod):
     # the LDS-tiled DMA-ring kernel instantiated for 1-, 2- and 8-tap stencils (frames 16-byte friendly)

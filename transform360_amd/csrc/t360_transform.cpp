@@ -271,6 +271,14 @@ bool VideoFrameTransform::ensureLanes() {
   return true;
 }
 
+// Per-map tables that depend on a call's plane size (low-pass tile lists, INTER_AREA tables) are rebuilt in place when a
+// later call names the map with another size; with pipelined calls in flight a lane may still be reading the old ones.
+bool VideoFrameTransform::quiesceLanes() {
+  bool any = false;
+  for (int k = 0; k < kMaxLanes; k++) any = any || (pipe_streams_[k] && pipe_busy_[k]);
+  return !any || check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+}
+
 bool VideoFrameTransform::drainLanes() {
   bool ok = true;
   for (int k = 0; k < kMaxLanes; k++)
@@ -400,6 +408,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
     return false;
   }
   DeviceGuard g(device_);
+  if (!quiesceLanes()) return false;  // a pipelined call on another lane may still be using this index's map and tables
   PlaneState& p = planes_[idx];
 
   MapGenParams P;
@@ -649,6 +658,7 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
 // (resize.cpp computeResizeAreaTab, evaluated in double like OpenCV does).
 bool VideoFrameTransform::buildResizePlan(PlaneState& p, int dw, int dh) {
   PlaneState::ResizePlan& r = p.resize;
+  if (r.dw >= 0 && !quiesceLanes()) return false;  // tables of a previous target size may be in use on another lane
   r.dw = dw;
   r.dh = dh;
   r.needed = p.map_w != dw || p.map_h != dh;
@@ -753,6 +763,8 @@ static bool same_run(const t360::Segment& a, const t360::Segment& b) {
 // VideoFrameTransform.cpp:630-691: every segment once per eye).
 bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex) {
   if (p.tiles_w == w && p.tiles_h == h) return true;
+  // the lists are about to be rewritten in place: a call still running on another pipeline lane may be reading them
+  if (p.tiles_w >= 0 && !quiesceLanes()) return false;
   std::vector<LowpassTile> tiles, fast_tiles, rest_tiles, wide_tiles;
   int max_rows_rest = 0, fast_lds = 0, wide_lds = 0;
   int ox[2] = {0, 0}, oy[2] = {0, 0}, eyes = 1;

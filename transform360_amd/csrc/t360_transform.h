@@ -182,6 +182,7 @@ class VideoFrameTransform {
   bool pipe_busy_[kMaxLanes] = {false, false, false, false};  // work issued on the lane since the last join
   bool ensureLanes();
   bool drainLanes();  // host-side wait for every lane
+  bool quiesceLanes();  // before per-map tables are rewritten in place: nothing may still be reading them
   t360::DeviceBuffer stage_in_, stage_out_;  // host-pointer path: device side
   t360::HostStager stager_;                  // ... the copies (contiguous where the strides allow; nothing is pinned or cached)
 };
