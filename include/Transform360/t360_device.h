@@ -116,7 +116,7 @@ int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i
 const char* T360_lastKernel(VideoFrameTransform* transform);
 /* Gather plan of `map_index` (the one long batches use): stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
  * by the staged tiles, bytes of LDS filled per frame (one copy), pixels in direct tiles, bytes of the tile
- * tables on the device, 0, 0.  Returns 0 when the plane has no tile plan (it then uses the general gather). */
+ * tables on the device, scatter tiles among the staged ones (0 in the shipped configuration), 0.  Returns 0 when the plane has no tile plan (it then uses the general gather). */
 int T360_getPlanStats(VideoFrameTransform* transform, int map_index, int64_t* stats8);
 /* 0 for the shipped library.  Non-zero for a library compiled with -DT360_INSTRUMENT, which reads tuning
  * switches from the environment (development only; bench.py refuses to report numbers from it). */

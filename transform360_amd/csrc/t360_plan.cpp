@@ -21,6 +21,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <thread>
 #include <utility>
 
@@ -656,7 +658,26 @@ class Planner {
     return plan_group(a, key, out, direct) && plan_group(b, key, out, direct);
   }
 
+  // A scatter group whose footprint cannot be staged even as single blocks (block_box() bounds a block's size, not its
+  // feasibility under the piece budget and the row alignment) sends the 128x32 output regions of its blocks back to the
+  // rectangular path and the plan is made again, instead of failing the whole plane into the general gather (ADVICE
+  // round 4).  Terminates: every retry grows `rect`, and with every region in it no scatter group exists.
   bool run(HostGatherPlan* out) const {
+    std::set<uint32_t> rect;
+    for (;;) {
+      std::vector<uint32_t> back;
+      *out = HostGatherPlan();
+      if (run_once(out, rect, &back)) return true;
+      if (back.empty()) return false;
+      const size_t before = rect.size();
+      rect.insert(back.begin(), back.end());
+      if (rect.size() == before) return false;
+    }
+  }
+
+  static uint32_t region_key(int rx, int ry) { return (uint32_t)rx | ((uint32_t)ry << 16); }
+
+  bool run_once(HostGatherPlan* out, const std::set<uint32_t>& rect, std::vector<uint32_t>* back) const {
     const int regions_x = (dw_ + region_w() - 1) / region_w(), regions_y = (dh_ + 31) / 32;
     const int band = std::max(1, opt_.band);
     // Emission order = execution order.  raster = false: region rows are walked in bands, column by column inside
@@ -669,7 +690,7 @@ class Planner {
       for (int ry0 = 0; ry0 < regions_y; ry0 += band)
         for (int rx = 0; rx < regions_x; rx++)
           for (int ry = ry0; ry < std::min(ry0 + band, regions_y); ry++) {
-            bool regular = scatter_on();
+            bool regular = scatter_on() && !rect.count(region_key(rx, ry));
             const size_t mark = pool.size();
             for (int oy = ry * 32; regular && oy < std::min(ry * 32 + 32, dh_); oy += 4)
               for (int ox = rx * 128; regular && ox < std::min(rx * 128 + 128, dw_); ox += 4) {
@@ -723,14 +744,18 @@ class Planner {
     // no exception may leave a worker (std::terminate) or this function (the C ABI returns 0/1): a slice that runs out
     // of memory marks the plan as failed, a thread that cannot be started has its slice planned here
     std::atomic<bool> failed{false};
+    std::mutex back_mu;
     auto work = [&](size_t ti) {
       try {
         const size_t lo = n * ti / nthreads, hi = n * (ti + 1) / nthreads;
         for (size_t i = lo; i < hi && !failed.load(std::memory_order_relaxed); i++) {
           if (i < regions.size())
             plan_region(regions[i].first, regions[i].second, &part[ti], &part_direct[ti]);
-          else if (!plan_group(groups[i - regions.size()].blocks, groups[i - regions.size()].key, &part[ti], &part_direct[ti]))
+          else if (!plan_group(groups[i - regions.size()].blocks, groups[i - regions.size()].key, &part[ti], &part_direct[ti])) {
+            std::lock_guard<std::mutex> lk(back_mu);
+            for (uint32_t o : groups[i - regions.size()].blocks) back->push_back(region_key((int)(o & 0xffffu) / 128, (int)(o >> 16) / 32));
             failed.store(true);
+          }
         }
       } catch (...) {
         failed.store(true);

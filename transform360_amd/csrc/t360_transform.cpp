@@ -1530,7 +1530,8 @@ bool VideoFrameTransform::planStats(int idx, int64_t* st) const {
   st[3] = g.stats.lds_bytes;
   st[4] = g.stats.direct_pixels;
   st[5] = (int64_t)(g.tiles.size() + g.tlut.size() + g.chunks.size());
-  st[6] = st[7] = 0;
+  st[6] = g.stats.n_scatter;  // tiles of a scatter plan that really are scatter tiles (instrumented build only: T360_SCATTER)
+  st[7] = 0;
   return true;
 }
 
