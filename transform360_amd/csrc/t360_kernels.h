@@ -69,7 +69,8 @@ struct TiledArgs {
   int k_lo, k_hi;           // instrumented build only (INCOMPLETE OUTPUT): only work items k_lo <= k < k_hi of every XCD run (k_hi 0 = all)
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
                             // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B,
-                            // bit6 every frame reads frame 0's source (L2 hits), bit7 no frame barrier, bit8 no output stores
+                            // bit6 every frame reads frame 0's source (L2 hits), bit7 no frame barrier, bit8 no output stores;
+                            // (right pixels) bit9 s_setprio 3 around the DMA issue, bit10 around the deferred store and the DMA issue
   unsigned long long* trace;  // instrumented build only: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   unsigned long long* phases; // instrumented build only: 2 x 8 cycle sums per workgroup (T360_PHASES)
 #endif

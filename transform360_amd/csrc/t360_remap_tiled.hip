@@ -660,11 +660,14 @@ __device__ __forceinline__ void tile_waves(const TiledArgs& a, const TiledPlane&
       T360_PHASE(0);                                                                                       \
       if (!T360_DBG(a, 7)) frame_barrier(); /* the frame is complete in LDS; everyone has left the previous frame's slot */ \
       T360_PHASE(1);                                                                                       \
+      if (T360_DBG(a, 10)) asm volatile("s_setprio 3");                                                    \
       if (i + S > 0) {                                                                                     \
         if (has_px && !T360_DBG(a, 8)) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store, all_live);       \
         d += pl.dst_frame_bytes;                                                                           \
       }                                                                                                    \
+      if (T360_DBG(a, 9)) asm volatile("s_setprio 3");                                                     \
       if (i + S + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + i + S + K - 1, ((S + K - 1) % K) * R::kSlot);  \
+      if (T360_DBG(a, 9) || T360_DBG(a, 10)) asm volatile("s_setprio 0");                                  \
       T360_PHASE(2);                                                                                       \
       if (has_px && !T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, S * R::kSlot>(px, lds, dword_store); \
       asm volatile("" : "+v"(pending));                                                                    \
