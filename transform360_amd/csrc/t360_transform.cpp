@@ -337,13 +337,20 @@ bool VideoFrameTransform::transformFramesPipelined(const uint8_t* d_in, int64_t 
   } else if (busy != hipSuccess) {
     return check(busy, "hipStreamQuery");
   }
-  hipStream_t saved = stream_;
+  // the call runs as a plain one whose stream and scratch set are the lane's; restored on every way out (the vectors of
+  // runPlanes may throw, and the C entry point turns that into a 0)
+  struct Restore {
+    VideoFrameTransform* t;
+    hipStream_t saved;
+    ~Restore() {
+      t->stream_ = saved;
+      t->scratch_ = 0;
+    }
+  } restore{this, stream_};
   stream_ = ls;
   scratch_ = 1 + lane;
-  const bool ok = transformFrames(d_in, in_frame_bytes, d_out, out_frame_bytes, n_frames, planes, n_planes);
-  stream_ = saved;
-  scratch_ = 0;
   pipe_busy_[lane] = true;
+  const bool ok = transformFrames(d_in, in_frame_bytes, d_out, out_frame_bytes, n_frames, planes, n_planes);
   pipe_next_ = (lane + 1) % pipe_depth_;
   return ok;
 }
