@@ -1088,7 +1088,10 @@ def main():
                              "rehearse these legs on CPU with --stub")
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
-    if world > 1:
+    # T360_FORCE_DIST=1: initialise the process group even for ONE rank, so that the launcher form of a multi-GPU run --
+    # RCCL init, context broadcast, barriers, all_reduce, all_gather, the rendezvous-store wait -- can be rehearsed on a
+    # one-GPU box (every collective is then trivial, every API call real)
+    if world > 1 or os.environ.get("T360_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
