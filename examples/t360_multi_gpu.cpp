@@ -123,8 +123,14 @@ int main(int argc, char** argv) {
   std::vector<int> device_of((size_t)workers);
   for (int w = 0; w < workers; w++) device_of[(size_t)w] = w % ndev;
   if (gather && !gather_possible(device_of)) {
-    printf("note: --gather needs one device per worker (RCCL refuses duplicate devices in a communicator): compute only\n");
-    gather = false;
+    if (workers == 1) {
+      // one worker has nobody to gather from: the communicator is still initialised and the (empty) groups are posted, so
+      // that the RCCL side of the driver can be exercised on a one-GPU box
+      printf("note: --gather with one worker: RCCL is initialised, there is nothing to move\n");
+    } else {
+      printf("note: --gather needs one device per worker (RCCL refuses duplicate devices in a communicator): compute only\n");
+      gather = false;
+    }
   }
   // weak scaling (default): F frames per worker and step; --total-frames T (BASELINE configs[4]: T = 64): the T frames of
   // a step are sharded over the workers in contiguous blocks, worker w owns [lo_w, hi_w)

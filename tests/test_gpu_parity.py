@@ -865,3 +865,13 @@ def test_native_multi_gpu_driver_matches_the_python_path(T):
         assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, F, t.plane_descs(lin, lout)) and t.synchronize()
         want = int(d_out.to(torch.int64).sum().item())
     assert got == want
+    # the same frames through the pipelined calls with the gather path on: one worker has nobody to gather from, but RCCL is
+    # initialised, the (empty) groups are posted and every step joins its lanes before the send would read the buffer
+    out = subprocess.run([exe, "--workers", "1", "--frames", str(F), "--steps", "4", "--pipelined", "2", "--gather"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert int(out.stdout.split("output checksum")[1].split()[0]) == want
+    # two workers sharing the device, BASELINE configs[4]-style sharding of 2 F frames: worker 0 owns frames [0, F)
+    out = subprocess.run([exe, "--workers", "2", "--total-frames", str(2 * F), "--steps", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert int(out.stdout.split("output checksum")[1].split()[0]) == want
