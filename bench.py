@@ -999,7 +999,10 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             "repeats": REPEATS, "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in runs],
             "clock_warmup_steps": clock_warmup_steps,
             "input_ring": {"groups_of_F_frames": getattr(path, "groups", 1), "bytes": getattr(path, "groups", 1) * F * lin.frame_bytes,
-                           "why": "timed steps rotate through this much distinct input when one step's input would fit the 256 MB Infinity Cache"},
+                           "why": "timed steps rotate through this much distinct input, several times the 256 MB Infinity Cache: a step "
+                                  "whose input fits the cache would find it there, and even re-reading ONE 708 MB batch of config 2 every "
+                                  "step measured 1 % faster than rotating through three (0.2370 vs 0.2395 ms, round 5, "
+                                  "tools/experiments_r05/call5.sh; rounds 1-4 did the former)"},
             "frames_timed_per_gpu": REPEATS * args.steps * F,
             # context for the timed region: `ms_per_step` x steps is a few milliseconds; over the
             # whole run this rank kept the GPU busy with transform steps (clock ramp, warm-up, every timed leg) for
