@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/soak/fuzz_soak.py [first_seed] [count] [plane|batch] -- the random configurations of tests/test_gpu_fuzz.py (single
+"""tests/soak/fuzz_soak.py [first_seed] [count] [plane|batch|pipe|plane4|tiny] -- the random configurations of tests/test_gpu_fuzz.py (single
 planes, or yuv420p batches) for seeds beyond the ones the suite pins (development soak; prints every mismatch, exits 1
 if there was one)."""
 import os
@@ -14,6 +14,8 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "plane"
 fn = F.test_random_batches_match_oracle if mode == "batch" else F.test_random_configuration_matches_oracle
+if mode == "pipe":   # random batches, plain and through three pipelined lanes
+    fn = lambda seed, oracle: F.test_random_batches_match_oracle(seed, oracle, pipelined=True)  # noqa: E731
 if mode == "tiny":
     # the same configurations on very small planes (1 .. 40 px a side, any alignment)
     small = F.draw

@@ -98,7 +98,7 @@ def test_random_configuration_matches_oracle(seed, oracle_mod):
 
 
 @pytest.mark.parametrize("seed", range(30))
-def test_random_batches_match_oracle(seed, oracle_mod):
+def test_random_batches_match_oracle(seed, oracle_mod, pipelined=False):
     """yuv420p batches through T360_transformFrames: frame counts around the frames-per-workgroup
     boundary, all three planes fused, against per-plane oracle calls."""
     from tests.test_gpu_parity import _batch_case
@@ -110,4 +110,11 @@ def test_random_batches_match_oracle(seed, oracle_mod):
     in_w, in_h = int(r.integers(6, 24)) * 32, int(r.integers(6, 20)) * 16
     out_w, out_h = int(r.integers(3, 16)) * 24, int(r.integers(3, 12)) * 16
     n = int(r.choice([1, 2, 3, 15, 16, 17, 20]))
-    _batch_case(T, oracle_mod, ov, n=n, dims=(in_w, in_h, out_w, out_h), extra_pad=int(r.choice([0, 0, 64, 40])))
+    _batch_case(T, oracle_mod, ov, n=n, dims=(in_w, in_h, out_w, out_h), extra_pad=int(r.choice([0, 0, 64, 40])), pipelined=pipelined)
+
+
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_random_batches_through_pipelined_calls(seed, oracle_mod):
+    """the same random batches, then three more times through T360_transformFramesPipelined on three lanes (low-pass and
+    supersample scratch per lane, overlapping launches): identical to the plain call, which is compared with the oracle"""
+    test_random_batches_match_oracle(seed, oracle_mod, pipelined=True)

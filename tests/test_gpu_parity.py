@@ -217,8 +217,9 @@ def test_filter_call_sequence_yuv420p(T, oracle_mod):
 
 
 # ---------------------------------------------------------------- batch entry point
-def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=4):
-    """n frames x 3 planes through T360_transformFrames == per-plane oracle calls."""
+def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=4, pipelined=False):
+    """n frames x 3 planes through T360_transformFrames == per-plane oracle calls.  pipelined: the same batch three more
+    times through T360_transformFramesPipelined (three lanes, three buffers) == the plain call's output, bit for bit."""
     import torch
     in_w, in_h, out_w, out_h = dims
     ctx = filter_defaults(**ov)
@@ -237,6 +238,15 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=
         assert t.setStream(torch.cuda.current_stream())
         assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
         assert t.synchronize()
+        if pipelined:
+            assert t.setPipelineDepth(3)
+            outs = [torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda") for _ in range(3)]
+            torch.cuda.synchronize()
+            for o3 in outs:
+                assert t.transformFramesPipelined(d_in, lin.frame_bytes, o3, lout.frame_bytes, n, t.plane_descs(lin, lout))
+            assert t.synchronize()
+            for o3 in outs:
+                assert torch.equal(o3, d_out), "a pipelined call differs from the plain one"
         h_in = d_in.cpu().numpy()
         h_out = d_out.cpu().numpy()
         for k in range(n):
