@@ -7,7 +7,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/transform360_amd/csrc
 O=$R/tools/ab/$NAME
 mkdir -p "$O"
-FL=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -I$R/include -I$S -DT360_INSTRUMENT "$@")
+# NOINSTR=1: a variant of the SHIPPED configuration (no tuning switches) -- bench.py then reports its numbers like the library's
+FL=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -I$R/include -I$S $([ "${NOINSTR:-0}" = 1 ] || echo -DT360_INSTRUMENT) "$@")
 for f in t360_mapgen.hip t360_remap.hip t360_remap_tiled.hip t360_lowpass.hip t360_resize.hip; do
   /opt/rocm/bin/hipcc "${FL[@]}" -c $S/$f -o $O/${f%.hip}.o &
 done

@@ -55,10 +55,18 @@ namespace {
 // class P >= p; its ring then holds K = min(4, ring / slot) frames.  Slot sizes are compile-time constants so
 // that the slot base is an immediate of the consumer's ds_read (the frame loop is unrolled over the K slots):
 // most tiles stage 4-8 KiB and keep 4 frames in the ring, the few large ones near the poles 2-3.
+// frames in the ring of a workgroup, at most (per ring size, for A/B builds).  3 = two frames' DMA in flight.  Round 5
+// (tools/experiments_r05/call17.sh, call18.sh): with 4 the DMA-only time of a 64-frame launch does not move (0.2237 -> 0.2239 ms:
+// the memory side is not bound by the bytes a workgroup has in flight) and the whole launch is 1.5 % FASTER in the instrumented
+// build but 1.5 % SLOWER in the shipped configuration (0.2386 -> 0.2421, three interleaved rounds at +-0.1 %: the frame loop is
+// unrolled over the slots); 8-frame steps lose with 4 in both.
 #ifndef T360_MAX_SLOTS
 #define T360_MAX_SLOTS 3
 #endif
-constexpr int kMaxSlots = T360_MAX_SLOTS;
+#ifndef T360_MAX_SLOTS_SMALL
+#define T360_MAX_SLOTS_SMALL 3
+#endif
+constexpr int max_slots_of(int ringkb) { return ringkb >= 64 ? T360_MAX_SLOTS : T360_MAX_SLOTS_SMALL; }
 // T360_DUAL: 1 = every chunk is staged twice (copy B four bytes further) so that each stencil-row window is ONE aligned
 // ds_read_b64; 0 = one copy, two aligned ds_read_b32 per window: twice the LDS read cycles, but half the LDS per frame in
 // flight.  The gather is bound by bytes in flight (HBM latency x bandwidth), not by LDS cycles: 0 measured faster.
@@ -89,7 +97,7 @@ struct Slot {
 template <int RINGKB, int P, bool DUAL>
 struct Cls {
   static constexpr int kFit = RINGKB * 1024 / Slot<P, DUAL>::kSlot;
-  static constexpr int K = kFit > kMaxSlots ? kMaxSlots : kFit;  // < 2: the class does not fit this ring
+  static constexpr int K = kFit > max_slots_of(RINGKB) ? max_slots_of(RINGKB) : kFit;  // < 2: the class does not fit this ring
 };
 // smallest class that holds `pieces`
 #define T360_FOR_CLASS(pieces, F)    \
