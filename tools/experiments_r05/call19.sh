@@ -7,6 +7,12 @@ O=$R/gpurun_out/r05_call19; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export T360_LIB=$R/tools/ab/libT360_blocked.so T360_BENCH_ALLOW_INSTRUMENTED=1
 B="python $R/bench.py --config 3 --steps 20 --warmup 3 --no-cpu-baseline --no-host-abi --no-native --no-two-streams --no-verify"
+# (first: the library really gathers from blocked planes, bit-exact)
+for BL in 0 1; do
+  T360_BLOCKED=$BL timeout 300 python $R/bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --no-host-abi --no-native --no-two-streams > $O/v.json 2> $O/v.err
+  python -c "
+import json; d = json.loads(open('$O/v.json').read().strip().splitlines()[-1]); print('T360_BLOCKED=$BL verified', d['verified']['max_abs_diff'], 'ms/step', d['ms_per_step'])"
+done
 for REP in 1 2; do
 for BL in 0 1; do
 for DBG in 0 1 2; do
