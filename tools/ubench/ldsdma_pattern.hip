@@ -6,6 +6,7 @@
 //   rows256   4 rows x 256 bytes, rows 3840 bytes apart            (an un-slanted footprint)
 //   rows96    ~11 rows x 96 bytes (6 chunks), unaligned start      (a slanted footprint near a face edge)
 //   rows32    32 rows x 32 bytes                                   (a polar footprint)
+//   rows208   ~5 rows x 208 bytes at a drifting, unaligned start   (the average footprint row of the bicubic gather; round 5)
 // Source: frames of 3840 x 1920 bytes, 64 of them (HBM), every workgroup its own region; or ONE frame (L2 / MALL resident).
 // Reports GB/s per CU and over the chip.  Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/ldsdma ldsdma_pattern.hip
 #include <hip/hip_runtime.h>
@@ -20,6 +21,8 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(512) void stage(const uint8_t* src, long frame_byte
     if (pattern == 0) o = piece * 1024 + lane * 16;                                          // contiguous
     else if (pattern == 1) o = (piece * 4 + lane / 16) * 3840 + (lane % 16) * 16;           // 4 rows x 256 B
     else if (pattern == 2) o = (piece * 11 + lane / 6) * 3840 + 40 + (lane % 6) * 16 + (lane / 6) * 16;  // ~11 rows x 96 B, drifting start
-    else o = (piece * 32 + lane / 2) * 3840 + (lane % 2) * 16 + (lane / 2 % 4) * 32;        // 32 rows x 32 B
+    else if (pattern == 3) o = (piece * 32 + lane / 2) * 3840 + (lane % 2) * 16 + (lane / 2 % 4) * 32;        // 32 rows x 32 B
+    else o = (piece * 5 + lane / 13) * 3840 + 24 + (lane % 13) * 16 + (lane / 13) * 48;      // ~5 rows x 208 B, drifting unaligned start (the gather; round 5)
     off[p] = (int)region + o;
   }
   const unsigned slot_bytes = 8 * PPW * 1024;
@@ -71,14 +75,14 @@ int main() {
   (void)hipMalloc(&src, frame_bytes * F + (4 << 20)); (void)hipMalloc(&out, 4);
   (void)hipMemset(src, 3, frame_bytes * F + (4 << 20));
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-  const char* names[] = {"contig", "rows256", "rows96", "rows32"};
+  const char* names[] = {"contig", "rows256", "rows96", "rows32", "rows208"};
   // 76 KiB of LDS per workgroup whatever the ring needs: two workgroups per CU, like the gather
   const size_t lds_bytes = 76 * 1024;
   for (int same = 0; same < 2; same++)
-    for (int cfg = 0; cfg < 5; cfg++)
-      for (int pat = 0; pat < 4; pat++) {
+    for (int cfg = 0; cfg < 8; cfg++)
+      for (int pat = 0; pat < 5; pat++) {
         float best = 1e9f;
-        static const int ppws[] = {1, 1, 1, 2, 2}, ds[] = {2, 4, 8, 2, 3};
+        static const int ppws[] = {1, 1, 1, 2, 2, 1, 2, 1}, ds[] = {2, 4, 8, 2, 3, 3, 4, 6};
         const int ppw = ppws[cfg], d = ds[cfg];
         for (int rep = 0; rep < 3; rep++) {
           (void)hipEventRecord(a);
@@ -88,7 +92,10 @@ int main() {
               case 1: hipLaunchKernelGGL((stage<1, 4>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
               case 2: hipLaunchKernelGGL((stage<1, 8>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
               case 3: hipLaunchKernelGGL((stage<2, 2>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
-              default: hipLaunchKernelGGL((stage<2, 3>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
+              case 4: hipLaunchKernelGGL((stage<2, 3>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
+              case 5: hipLaunchKernelGGL((stage<1, 3>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
+              case 6: hipLaunchKernelGGL((stage<2, 4>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
+              default: hipLaunchKernelGGL((stage<1, 6>), dim3(512), dim3(512), lds_bytes, 0, src, frame_bytes, F, pat, same, out); break;
             }
           }
           (void)hipEventRecord(b); (void)hipEventSynchronize(b);
