@@ -274,6 +274,24 @@ def test_bench_rank_function_world_size_2_gloo():
     assert x["bytes_from_rank0_per_step"] > x["bytes_to_rank0_per_step"] > 0 and x["ms_per_step"] > 0
 
 
+def test_bench_headline_is_strong_scaling_with_two_ranks():
+    """With N > 1 ranks and the default 64 frames per step the line's `value` is BASELINE configs[4] as written -- 64 frames per
+    step in total, 32 per rank here, "scaling": "strong" -- and the weak figure is a sub-record."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", T360_DIST_BACKEND="gloo")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29743", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "2",
+         "--warmup", "1"], env=env, stderr=subprocess.DEVNULL, timeout=300, cwd=ROOT).decode()
+    rec = json.loads([line for line in out.splitlines() if line.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["frames_per_step_total"] == 64 and rec["config"]["frames_per_step_per_gpu"] == 32
+    s, w = rec["strong_cfg5"], rec["weak_64_frames_per_gpu"]
+    assert rec["value"] == s["value"] == rec["strong_cfg5_value"] and rec["ms_per_step"] == s["ms_per_step"]
+    assert w["scaling"] == "weak" and w["frames_per_step_per_gpu"] == 64 and rec["weak_value"] == w["value"]
+    assert rec["roofline"]["algorithmic_bytes_per_launch"] > 0 and rec["roofline"]["avg_launch_ms"] > 0
+
+
 def test_native_multi_gpu_driver_bookkeeping(tmp_path):
     """examples/t360_shard_plan.h -- the frame ranges, the per-step send / recv lists and the buffer alternation of the
     native multi-GPU driver (examples/t360_multi_gpu.cpp) -- compiled with g++ and checked without HIP or RCCL
