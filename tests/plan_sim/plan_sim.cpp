@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "t360_filtercfg.h"
 #include "t360_plan.h"
 
 extern "C" int t360_plan_sim(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces,
@@ -193,4 +194,203 @@ extern "C" int t360_pack_weights(const short* tab, int ks, unsigned* out) {
   t360::pack_weights(t, ks, &v);
   memcpy(out, v.data(), v.size() * sizeof(uint32_t));
   return (int)v.size();
+}
+
+// ---- fused low-pass tiles (round 6) ------------------------------------------------------------------------------------
+// CPU emulation of remap_fused_kernel THROUGH the plan: every fused tile's R chunk table is staged from the RAW source into a
+// fake LDS slot, every lane's run is filtered with the kernel's integer arithmetic (aligned dwords, the byte-shifted tap
+// variants, r = SUM kx*p, c = SUM ky*r, (c + 32768) >> 16 saturated) out of the R rows the R row table names, the blurred
+// dwords are written IN PLACE at the B positions, and every pixel's stencil bytes found there are compared with `blurred`
+// (the whole plane filtered by the oracle).  The UNFUSED tiles of the same plan are staged from a copy of `blurred` in which
+// every segment the plan does NOT list as needed is inverted: a tap that lands there is an error.  Also: every output
+// pixel is covered exactly once over both work lists.  Returns the number of violations; stats[0..3] = fused tiles, unfused
+// staged tiles, direct tiles, needed segments.
+extern "C" long long t360_plan_verify_fused(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces,
+                                            const unsigned char* src, const unsigned char* blurred, const int* seg_rects,
+                                            int nsegs, const short* row_kid, const unsigned* taps, long long* stats) {
+  using namespace t360;
+  FuseInfo fi;
+  fi.row_kid.assign(row_kid, row_kid + sh);
+  for (int i = 0; i < nsegs; i++) fi.segs.push_back({seg_rects[4 * i], seg_rects[4 * i + 1], seg_rects[4 * i + 2], seg_rects[4 * i + 3]});
+  PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces;
+  o.waves = 8;
+  o.fuse = &fi;
+  HostGatherPlan plan;
+  if (!plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
+  auto wrapi = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
+  const int lo = ks == 1 ? 0 : ks / 2 - 1;
+  const int mp = max_pieces < kMaxPieces ? max_pieces : kMaxPieces;
+  const size_t wstride = (size_t)tile_words(ks, 8);
+  long long bad = 0;
+  auto complain = [&](const char* what, int tile, int px, int py) {
+    if (bad++ < 8) printf("plan_verify_fused: %s (tile %d, output pixel %d,%d)\n", what, tile, px, py);
+  };
+  std::vector<unsigned char> cover((size_t)dw * dh, 0);
+  std::vector<unsigned char> lds;
+  auto shape_of = [&](const TileDesc& t, int* w, int* h, int* lanes, int* npx) {
+    *lanes = 256; *npx = 4;
+    switch (t.kind) {
+      case kTileStaged32: *w = 32; *h = 32; return true;
+      case kTileStaged16: *w = 16; *h = 16; *npx = 1; return true;
+      case kTileStrip128: *w = 128; *h = 8; return true;
+      case kTileWide64: *w = 64; *h = 16; return true;
+      case kTileWide128: *w = 128; *h = 16; *lanes = 512; return true;
+      default: return false;
+    }
+  };
+  // pixels of a tile against `want_plane`, their stencil bytes looked up in `lds` through row table `rowtab`
+  auto check_pixels = [&](const TileDesc& t, int ti, const uint32_t* words, const uint32_t* rowtab, const unsigned char* want_plane) {
+    int w, h, lanes, npx;
+    if (!shape_of(t, &w, &h, &lanes, &npx)) { complain("unknown tile kind", ti, t.ox, t.oy); return; }
+    auto row_base = [&](int r) { return (int)(int16_t)(rowtab[(size_t)(r >> 1)] >> (16 * (r & 1))); };
+    for (int tid = 0; tid < lanes; tid++)
+      for (int p = 0; p < npx; p++) {
+        const int px = npx == 4 ? t.ox + tid % w : t.ox + (tid & 15), py = npx == 4 ? t.oy + (tid / w) * 4 + p : t.oy + (tid >> 4);
+        const uint32_t word = words[(size_t)tid * 4 + p];
+        if (!(px < dw && py < dh && py < t.oy + h)) {
+          if (!(word >> 31)) complain("live pixel word outside the plane", ti, px, py);
+          continue;
+        }
+        if (word >> 31) { complain("dead pixel word inside the plane", ti, px, py); continue; }
+        cover[(size_t)py * dw + px]++;
+        const LutEntry& e = lut[(size_t)py * dw + px];
+        const int x = (int)(word & 2047u), row = (int)((word >> kWordRowShift) & 255u);
+        for (int k = 0; k < ks; k++) {
+          const int off = row_base(row + k) * kStageChunk + x;
+          for (int c = 0; c < ks; c++) {
+            const unsigned char want = want_plane[(size_t)wrapi((int)e.iy - lo + k, sh) * sw + (size_t)wrapi((int)e.ix - lo + c, sw)];
+            if (off + c < 0 || (size_t)(off + c) >= lds.size() || lds[(size_t)(off + c)] != want) {
+              complain("byte under a stencil tap differs from the blurred plane", ti, px, py);
+              k = ks;
+              break;
+            }
+          }
+        }
+      }
+  };
+  // ---- fused tiles ----
+  const size_t fcs = (size_t)fused_chunk_dwords(mp);
+  for (int ti = 0; ti < plan.nftiles; ti++) {
+    const TileDesc& t = plan.ftiles[(size_t)ti];
+    const uint32_t* tc = &plan.fchunks[(size_t)ti * fcs];
+    const uint32_t* btab = tc + (size_t)mp * kPieceChunks;
+    const uint32_t* rtab = btab + 64;
+    const uint32_t* runs = rtab + 64;
+    const uint32_t* winfo = runs + kFusedLanes;
+    if (!(t.flags & kTileFused) || t.pieces <= 0 || t.pieces > mp) complain("fused tile descriptor", ti, t.ox, t.oy);
+    lds.assign((size_t)t.pieces * 1024, 0);
+    for (int pos = 0; pos < t.pieces * kPieceChunks; pos++) {
+      const uint32_t e = tc[pos];
+      const int sy = (int)(e >> 12), cx = (int)(e & 4095u);
+      if (sy >= sh || (cx + 1) * kStageChunk > sw) { complain("chunk entry outside the source plane", ti, t.ox, t.oy); continue; }
+      memcpy(&lds[(size_t)pos * kStageChunk], src + (size_t)sy * sw + (size_t)cx * kStageChunk, kStageChunk);
+    }
+    auto rbase = [&](int tr) { return (int)(int16_t)(rtab[(size_t)(tr >> 1)] >> (16 * (tr & 1))); };
+    auto bbase = [&](int r) { return (int)(int16_t)(btab[(size_t)(r >> 1)] >> (16 * (r & 1))); };
+    const int ni = (int)winfo[8];
+    std::vector<std::pair<int, uint32_t>> writes;
+    for (int lane = 0; lane < kFusedLanes; lane++) {
+      const uint32_t rw = runs[lane];
+      if (rw >> 31) { complain("idle lane in a fused tile", ti, t.ox, t.oy); continue; }
+      const int dcol = (int)(rw & 511u), r0 = (int)((rw >> 9) & 127u), len = (int)((rw >> 16) & 15u);
+      if (len < 1 || len > ni || r0 + len > t.rows) { complain("run word", ti, t.ox, t.oy); continue; }
+      const uint32_t* tp = taps + (size_t)winfo[lane / 64] * kFusedTapDwords;
+      const uint32_t V[4][3] = {{tp[0], tp[1], 0}, {tp[2], tp[3], tp[4]}, {tp[5], tp[6], tp[7]}, {0, tp[8], tp[9]}};
+      uint32_t res[3][4] = {{0}};
+      for (int i = 0; i < len + 2; i++) {
+        const int a = rbase(r0 + i) * kStageChunk + kStageChunk + 4 * dcol - 4;
+        uint32_t d[3] = {0, 0, 0};
+        if (a < 0 || (size_t)(a + 12) > lds.size()) { complain("filter read outside the slot", ti, t.ox, t.oy); break; }
+        memcpy(d, &lds[(size_t)a], 12);
+        if (rw & kRunLeftEdge) d[0] = (d[1] & 255u) * 0x01010101u;
+        if (rw & kRunRightEdge) d[2] = (d[1] >> 24) * 0x01010101u;
+        for (int j = 0; j < 4; j++) {
+          uint32_t acc = 0;
+          for (int q = 0; q < 3; q++)
+            for (int b = 0; b < 4; b++) acc += ((d[q] >> (8 * b)) & 255u) * ((V[j][q] >> (8 * b)) & 255u);
+          res[i % 3][j] = acc;
+        }
+        if (i >= 2) {
+          uint32_t out = 0;
+          for (int j = 0; j < 4; j++) {
+            uint32_t c = (1u << 15) + tp[10] * res[(i - 2) % 3][j] + tp[11] * res[(i - 1) % 3][j] + tp[12] * res[i % 3][j];
+            c >>= 16;
+            out |= (c > 255u ? 255u : c) << (8 * j);
+          }
+          writes.push_back({bbase(r0 + i - 2) * kStageChunk + 4 * dcol, out});
+        }
+      }
+    }
+    for (const auto& wv : writes) {
+      if (wv.first < 0 || (size_t)(wv.first + 4) > lds.size()) { complain("blurred dword outside the slot", ti, t.ox, t.oy); continue; }
+      memcpy(&lds[(size_t)wv.first], &wv.second, 4);
+    }
+    check_pixels(t, ti, &plan.ftlut[(size_t)ti * wstride], btab, blurred);
+  }
+  // ---- unfused tiles: staged from the blurred plane with every segment nobody asked for inverted ----
+  std::vector<unsigned char> partial(blurred, blurred + (size_t)sw * sh);
+  int needed = 0;
+  for (int i = 0; i < nsegs; i++) {
+    const bool need = (size_t)i < plan.seg_needed.size() && plan.seg_needed[(size_t)i];
+    needed += need;
+    if (need) continue;
+    for (int y = seg_rects[4 * i + 1]; y < seg_rects[4 * i + 1] + seg_rects[4 * i + 3]; y++)
+      for (int x = seg_rects[4 * i]; x < seg_rects[4 * i] + seg_rects[4 * i + 2]; x++) partial[(size_t)y * sw + x] ^= 0xff;
+  }
+  const size_t cstride = (size_t)tile_chunk_dwords(mp, false);
+  for (int ti = 0; ti < plan.ntiles; ti++) {
+    const TileDesc& t = plan.tiles[(size_t)ti];
+    const uint32_t* tc = &plan.chunks[(size_t)ti * cstride];
+    lds.assign((size_t)t.pieces * 1024, 0);
+    for (int pos = 0; pos < t.pieces * kPieceChunks; pos++) {
+      const uint32_t e = tc[pos];
+      const int sy = (int)(e >> 12), cx = (int)(e & 4095u);
+      if (sy >= sh || (cx + 1) * kStageChunk > sw) { complain("chunk entry outside the source plane", ti, t.ox, t.oy); continue; }
+      memcpy(&lds[(size_t)pos * kStageChunk], partial.data() + (size_t)sy * sw + (size_t)cx * kStageChunk, kStageChunk);
+    }
+    check_pixels(t, 100000 + ti, &plan.tlut[(size_t)ti * wstride], tc + (size_t)mp * kPieceChunks, blurred);
+  }
+  for (int i = 0; i < plan.ndirect; i++) {
+    const TileDesc& t = plan.tiles[(size_t)plan.ntiles + (size_t)i];
+    for (int y = t.oy; y < t.oy + 16 && y < dh; y++)
+      for (int x = t.ox; x < t.ox + 16 && x < dw; x++) {
+        cover[(size_t)y * dw + x]++;
+        const LutEntry& e = lut[(size_t)y * dw + x];
+        for (int k = 0; k < ks; k++)
+          for (int c = 0; c < ks; c++) {
+            const size_t at = (size_t)wrapi((int)e.iy - lo + k, sh) * sw + (size_t)wrapi((int)e.ix - lo + c, sw);
+            if (partial[at] != blurred[at]) { complain("direct tile reads a segment that is not listed as needed", -2, x, y); k = ks; break; }
+          }
+      }
+  }
+  for (int y = 0; y < dh; y++)
+    for (int x = 0; x < dw; x++)
+      if (cover[(size_t)y * dw + x] != 1) complain("output pixel not covered exactly once", -1, x, y);
+  if (stats) {
+    stats[0] = plan.nftiles; stats[1] = plan.ntiles; stats[2] = plan.ndirect; stats[3] = needed;
+    stats[4] = plan.stats.fused_raw_bytes; stats[5] = plan.stats.fused_blurred_bytes; stats[6] = plan.stats.fused_run_slots;
+    stats[7] = plan.stats.fetched_bytes;
+  }
+  return bad;
+}
+
+// build_fuse_info() of the library for a context: returns the number of kernels (0: nothing fusable); row_kid[h], rects[4 * cap],
+// taps[kFusedTapDwords * cap_k]
+extern "C" int t360_host_fuse_info(const FrameTransformContext* ctx, int inW, int inH, int outW, int outH, short* row_kid,
+                                   int* rects, int cap, unsigned* taps, int cap_k, int* nsegs) {
+  t360::FilterConfig cfg;
+  if (!t360::build_filter_config(*ctx, inW, inH, outW, outH, &cfg)) return -1;
+  t360::FuseInfo fi;
+  std::vector<uint32_t> packed;
+  const bool any = t360::build_fuse_info(*ctx, cfg, inW, inH, &fi, &packed);
+  *nsegs = (int)fi.segs.size();
+  if ((int)fi.segs.size() > cap || (int)(packed.size() / t360::kFusedTapDwords) > cap_k) return -2;
+  for (size_t i = 0; i < fi.segs.size(); i++) {
+    rects[4 * i] = fi.segs[i].left; rects[4 * i + 1] = fi.segs[i].top; rects[4 * i + 2] = fi.segs[i].width; rects[4 * i + 3] = fi.segs[i].height;
+  }
+  for (int y = 0; y < inH; y++) row_kid[y] = fi.row_kid[(size_t)y];
+  memcpy(taps, packed.data(), packed.size() * sizeof(uint32_t));
+  return any ? (int)(packed.size() / t360::kFusedTapDwords) : 0;
 }

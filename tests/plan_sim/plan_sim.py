@@ -21,10 +21,12 @@ sys.path.insert(0, ROOT)
 
 def build():
     so = os.path.join(HERE, "libplansim.so")
-    srcs = [os.path.join(HERE, "plan_sim.cpp"), os.path.join(ROOT, "transform360_amd", "csrc", "t360_plan.cpp")]
+    srcs = [os.path.join(HERE, "plan_sim.cpp"), os.path.join(ROOT, "transform360_amd", "csrc", "t360_plan.cpp"),
+            os.path.join(ROOT, "transform360_amd", "csrc", "t360_filtercfg.cpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs + [
             os.path.join(ROOT, "transform360_amd", "csrc", "t360_plan.h"),
-            os.path.join(ROOT, "transform360_amd", "csrc", "t360_internal.h")]):
+            os.path.join(ROOT, "transform360_amd", "csrc", "t360_internal.h"),
+            os.path.join(ROOT, "transform360_amd", "csrc", "t360_filtercfg.h")]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "transform360_amd", "csrc")] + srcs + ["-o", so])
     L = C.CDLL(so)

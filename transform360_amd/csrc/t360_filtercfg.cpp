@@ -20,6 +20,7 @@
 // overloads (cos(angle) is cosf) and mixed expressions promote to double -- both are spelled
 // out below.  Built with -ffp-contract=off.
 #include "t360_filtercfg.h"
+#include "t360_plan.h"
 
 #include <cfloat>
 #include <cmath>
@@ -184,6 +185,80 @@ int pack_shifted_taps(const std::vector<int>& kx_q8, std::vector<uint32_t>* out)
       out->push_back(w);
     }
   return nd;
+}
+
+void pack_fused_taps(const std::vector<int>& kx_q8, const std::vector<int>& ky_q8, uint32_t* out) {
+  // horizontal taps zero-padded to 7 and centred; variant j (output byte j of the dword) holds tap k at byte 1 + j + k of
+  // the 12-byte window that starts 4 bytes left of the output dword
+  int k7[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int n = (int)kx_q8.size(), pad = (7 - n) / 2;
+  for (int k = 0; k < n; k++) k7[pad + k] = kx_q8[(size_t)k];
+  uint32_t v[4][3];
+  for (int j = 0; j < 4; j++)
+    for (int d = 0; d < 3; d++) {
+      uint32_t w = 0;
+      for (int b = 0; b < 4; b++) {
+        const int k = 4 * d + b - (1 + j);
+        if (k >= 0 && k < 7) w |= (uint32_t)k7[k] << (8 * b);
+      }
+      v[j][d] = w;
+    }
+  // the dwords that can be non-zero: v0: 0,1  v1: 0,1,2  v2: 0,1,2  v3: 1,2
+  const uint32_t packed[10] = {v[0][0], v[0][1], v[1][0], v[1][1], v[1][2], v[2][0], v[2][1], v[2][2], v[3][1], v[3][2]};
+  for (int i = 0; i < 10; i++) out[i] = packed[i];
+  for (int i = 0; i < 3; i++) out[10 + i] = (uint32_t)ky_q8[(size_t)i];
+  for (int i = 13; i < kFusedTapDwords; i++) out[i] = 0;
+}
+
+bool build_fuse_info(const FrameTransformContext& ctx, const FilterConfig& cfg, int w, int h, FuseInfo* info,
+                     std::vector<uint32_t>* packed_taps) {
+  info->row_kid.assign((size_t)std::max(h, 0), -1);
+  info->segs.clear();
+  packed_taps->clear();
+  if (ctx.input_stereo_format == STEREO_FORMAT_LR || ctx.input_stereo_format == STEREO_FORMAT_TB || w <= 0 || h <= 0) return false;
+  std::vector<std::pair<std::vector<int>, std::vector<int>>> kernels;
+  std::vector<int> seg_kid;
+  for (const Segment& s : cfg.segments) {
+    // (a segment outside the plane makes the reference print a message and skip it: nothing is fused then)
+    if (s.left < 0 || s.top < 0 || s.width < 0 || s.height < 0 || s.left + s.width > w || s.top + s.height > h) return false;
+    info->segs.push_back({s.left, s.top, s.width, s.height});
+    bool ok = s.fixed_point && s.kx_q8.size() <= 7 && (s.kx_q8.size() & 1) == 1 && s.ky_q8.size() == 3;
+    for (int v : s.kx_q8) ok = ok && v >= 0 && v <= 255;
+    for (int v : s.ky_q8) ok = ok && v >= 0 && v <= 256;
+    int kid = -1;
+    if (ok) {
+      for (size_t k = 0; k < kernels.size() && kid < 0; k++)
+        if (kernels[k].first == s.kx_q8 && kernels[k].second == s.ky_q8) kid = (int)k;
+      if (kid < 0 && kernels.size() < 32767) {
+        kid = (int)kernels.size();
+        kernels.push_back({s.kx_q8, s.ky_q8});
+      }
+    }
+    seg_kid.push_back(kid);
+  }
+  // a row is fusable when the segments on it cover it exactly and share one fusable kernel
+  std::vector<int64_t> covered((size_t)h, 0);
+  std::vector<int> kid_of((size_t)h, -2);  // -2: no segment seen yet
+  for (size_t i = 0; i < cfg.segments.size(); i++) {
+    const Segment& s = cfg.segments[i];
+    for (int y = s.top; y < s.top + s.height; y++) {
+      covered[(size_t)y] += s.width;
+      kid_of[(size_t)y] = kid_of[(size_t)y] == -2 ? seg_kid[i] : (kid_of[(size_t)y] == seg_kid[i] ? seg_kid[i] : -1);
+    }
+  }
+  bool any = false;
+  // (segments of one plane never overlap.)  A plane its segments do not cover keeps filterPlane's zeros where nothing is
+  // written (:625): the partial low-pass lists of a fused plan do not reproduce that, so nothing is fused then
+  for (int y = 0; y < h; y++)
+    if (covered[(size_t)y] != w) return false;
+  for (int y = 0; y < h; y++)
+    if (kid_of[(size_t)y] >= 0) {
+      info->row_kid[(size_t)y] = (int16_t)kid_of[(size_t)y];
+      any = true;
+    }
+  packed_taps->assign(std::max<size_t>(kernels.size(), 1) * kFusedTapDwords, 0);
+  for (size_t k = 0; k < kernels.size(); k++) pack_fused_taps(kernels[k].first, kernels[k].second, &(*packed_taps)[k * kFusedTapDwords]);
+  return any;
 }
 
 static bool build_filter_config_or_throw(const FrameTransformContext& c, int inputWidth, int inputHeight, int outputWidth,

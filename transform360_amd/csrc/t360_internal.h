@@ -105,6 +105,8 @@ enum : int {
 enum : int {
   kTilePartial = 1,    // crosses the right/bottom plane edge: per-pixel bounds checks, byte stores
   kTileSeamShift = 2,  // staged x coordinates use (x >= W/2 ? x - W : x): the tile straddles the +-180 degree seam
+  kTileFused = 4,      // low-pass fused tile (remap_fused_kernel): the DMA stages the RAW, dilated footprint and the
+                       // workgroup filters it in LDS before it gathers; see "fused low-pass tiles" below
 };
 
 constexpr int kStageChunk = 16;   // bytes per staged chunk (one dwordx4 per DMA lane)
@@ -150,6 +152,37 @@ constexpr int kBoxMaxCols = 2048 / 16;  // chunk columns of a box
 constexpr int kBoxMaxRows = 128;        // rows of a box: the row table is 64 dwords, one per lane of a wave
 // Chunk table entry: source row (already wrapped) and 16-byte column (already wrapped) of one LDS position.
 inline uint32_t chunk_entry(uint32_t sy, uint32_t cx) { return (sy << 12) | cx; }
+
+// ---- fused low-pass tiles (t360_remap_tiled.hip: remap_fused_kernel; planned by t360_plan.cpp) ----
+// For tiles whose source rows all lie in low-pass segments with fixed-point kernels of <= 7 horizontal and exactly 3
+// vertical taps (BASELINE config 3: every row between +-66 degrees of latitude) the blurred plane never goes through HBM:
+// the DMA stages the RAW footprint dilated by the kernel radius (R), the workgroup computes the blurred footprint (B) from
+// it in LDS -- same arithmetic as lowpass_q8w_kernel: r = SUM kx_q8 * p, c = SUM ky_q8 * r, sat_u8((c + 32768) >> 16) --
+// writes it IN PLACE into the same ring slot (after a barrier: every R byte has been read), and gathers from it.
+// Per-tile tables of a fused plan, at a fixed stride (fused_chunk_dwords):
+//   [R chunk table: 64 * max_pieces entries][B row table: 64 dwords][R row table: 64 dwords][run words: 512][wave info: 16]
+// B row table: int16 per B row, as in an unfused plan.  R row table: int16 per R row t = 0 .. rows + 1 (source row
+// y0 - 1 + t, clamped to the plane: BORDER_REPLICATE at the plane's top and bottom edge): LDS chunk position of the row
+// minus its first staged chunk column, relative to the R box origin (one chunk left of the B box origin).
+// Run word of lane l (one vertical run of <= kFusedMaxRun blurred dwords per lane and frame, all in ONE kernel band):
+//   bits 0..8    dword column of the run inside the B box (byte x = 4 * column)
+//   bits 9..15   first B row of the run
+//   bits 16..19  rows in the run (1 .. kFusedMaxRun)
+//   bit 20 / 21  the run is the plane's first / last dword column: the dword left / right of it is BORDER_REPLICATE, not
+//                what the (wrapping) gather footprint holds there
+//   bit 31       no run on this lane (never set in a plan: lanes without work of their own repeat a run of their wave --
+//                the same bytes written twice -- so the filter phase needs no per-lane predicates)
+// Wave info: dword w (0..7) = kernel index of wave w's runs (every wave's runs share one kernel: its taps sit in SGPRs),
+// dword 8 = the longest run of the tile.
+constexpr int kFusedMaxRun = 8;
+constexpr int kFusedLanes = 512;
+constexpr int fused_chunk_dwords(int max_pieces) { return max_pieces * 64 + 64 + 64 + kFusedLanes + 16; }
+constexpr uint32_t kRunDead = 0x80000000u, kRunLeftEdge = 1u << 20, kRunRightEdge = 1u << 21;
+// Packed taps of one fusable kernel (kFusedTapDwords dwords): the horizontal taps, zero-padded to 7 and centred, as the
+// four byte-shifted variants of a 12-byte window that starts 4 bytes left of the output dword -- variant j (output byte
+// j) holds tap k at window byte 1 + j + k: [v0.d0 v0.d1 | v1.d0 v1.d1 v1.d2 | v2.d0 v2.d1 v2.d2 | v3.d1 v3.d2] -- then
+// the three vertical taps as plain integers.
+constexpr int kFusedTapDwords = 16;  // 10 + 3, padded to a 64-byte s_load_dwordx16
 
 // Weights re-packed for v_dot4, per sub-pixel phase of a KS x KS interpolation:
 //   [KS*WIN signed high-byte dwords: w >> 8][KS*WIN unsigned low-byte dwords: w & 255]

@@ -82,6 +82,17 @@ hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream);
 // the instantiation launch_remap_tiled() picks for these parameters (reporting)
 const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves);
 
+// ---- LDS-tiled gather with the low-pass FUSED in (t360_remap_tiled.hip: remap_fused_kernel; t360_internal.h "fused
+// low-pass tiles") ----
+// `base` describes the launch like a launch of the tiled kernel: plane[k].src is the RAW source plane, tiles / tlut / chunks
+// are the FUSED work list of the plan (tables at fused_chunk_dwords(max_pieces)), ntiles its length, ndirect 0; taps[k] =
+// the plane's packed fusable kernels (kFusedTapDwords dwords each).  Bilinear and bicubic, workgroups of 8 waves, 76 KiB rings.
+struct FusedArgs {
+  TiledArgs base;
+  const uint32_t* taps[4];
+};
+hipError_t launch_remap_fused(const FusedArgs& a, hipStream_t stream);
+
 // ---- segmented separable low-pass (t360_lowpass.hip) ----
 struct LowpassArgs {
   const uint8_t* src;

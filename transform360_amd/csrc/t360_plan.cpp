@@ -76,6 +76,18 @@ class Planner {
     lo_ = opt.ks == 1 ? 0 : opt.ks / 2 - 1;  // taps of a ks-wide stencil: -(ks/2-1) .. +ks/2 around the LUT's
     hi_ = opt.ks == 1 ? 0 : opt.ks / 2;      // integer coordinate (nearest: the pixel itself)
     max_pos_ = std::min(opt.max_pieces, kMaxPieces) * kPieceChunks;
+    if (fuse_on()) {
+      // segments that intersect a source row, by row (the unfused tiles' "which blurred segments do I read" lookup)
+      row_segs_.assign((size_t)sh_, {});
+      for (size_t i = 0; i < opt_.fuse->segs.size(); i++) {
+        const FuseSegment& g = opt_.fuse->segs[i];
+        for (int y = std::max(0, g.top); y < std::min(sh_, g.top + g.height); y++) row_segs_[(size_t)y].push_back((int)i);
+      }
+    }
+  }
+  bool fuse_on() const {
+    return opt_.fuse != nullptr && opt_.waves == 8 && (opt_.ks == 2 || opt_.ks == 4) && (int)opt_.fuse->row_kid.size() == sh_ &&
+           opt_.scatter <= 0;
   }
 
   // the output pixel (if any) that lane `tid` holds as its pixel `p`
@@ -378,8 +390,219 @@ class Planner {
     return total;
   }
 
+  // pixel words of tile f in the lane order of the gather, at w[0 .. tile_words)
+  void pixel_words(const Foot& f, uint32_t* w) const {
+    const TileShape& s = f.shape;
+    const int per_lane = opt_.ks == 8 ? 1 : 4;
+    for (int tid = 0; tid < s.lanes; tid++)
+      for (int p = 0; p < s.npx; p++) {
+        int px, py;
+        if (!pixel_of_lane(f, tid, p, &px, &py)) continue;
+        const LutEntry& e = lut_[(size_t)py * dw_ + px];
+        int sx = e.ix;
+        if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
+        const uint32_t xrel = (uint32_t)(sx - lo_ - f.c0 * kStageChunk);
+        const uint32_t r0 = (uint32_t)(e.iy - lo_ - f.y0);
+        w[tid * per_lane + p] = xrel | (r0 << kWordRowShift) | ((uint32_t)e.frac << kWordFracShift);
+      }
+  }
+
+  // ---- fused low-pass tiles (t360_internal.h) ---------------------------------------------------------------------
+  // Marks the segments whose BLURRED pixels the (unfused) tile reads: its staged rows, or -- a direct tile -- its stencils.
+  void mark_needed(const Foot& f, bool direct, HostGatherPlan* out) const {
+    if (out->seg_needed.size() != opt_.fuse->segs.size()) out->seg_needed.assign(opt_.fuse->segs.size(), 0);
+    auto mark = [&](int y, int xa, int xb) {  // source row y (wrapped), pixel columns xa..xb inside the plane
+      for (int si : row_segs_[(size_t)y]) {
+        const FuseSegment& g = opt_.fuse->segs[(size_t)si];
+        if (g.left <= xb && g.left + g.width > xa) out->seg_needed[(size_t)si] = 1;
+      }
+    };
+    auto mark_wrapped = [&](int y, int xa, int xb) {  // xa..xb in unwrapped coordinates, at most one plane wide
+      y = wrap(y, sh_);
+      if (xb - xa + 1 >= sw_) return mark(y, 0, sw_ - 1);
+      const int a = wrap(xa, sw_), b = wrap(xb, sw_);
+      if (a <= b) return mark(y, a, b);
+      mark(y, a, sw_ - 1);
+      mark(y, 0, b);
+    };
+    if (direct) {
+      for_pixels(f, [&](int x, int y) {
+        const LutEntry& e = lut_[(size_t)y * dw_ + x];
+        for (int r = e.iy - lo_; r <= e.iy + hi_; r++) mark_wrapped(r, e.ix - lo_, e.ix + hi_);
+      });
+      return;
+    }
+    for (int r = 0; r < f.rows; r++)
+      if (f.first[(size_t)r] >= 0)
+        mark_wrapped(f.y0 + r, (f.c0 + f.first[(size_t)r]) * kStageChunk, (f.c0 + f.last[(size_t)r]) * kStageChunk + kStageChunk - 1);
+  }
+
+  // The tile as a FUSED tile, if it can be one: appended to out->ftiles / ftlut / fchunks.  f is placed (B layout).
+  bool emit_fused(Foot& f, HostGatherPlan* out) const {
+    const TileShape& s = f.shape;
+    const std::vector<int16_t>& row_kid = opt_.fuse->row_kid;
+    static const bool dbg = getenv("T360_PLAN_DEBUG") != nullptr;
+    auto why = [&](const char* w) { if (dbg) printf("unfused %s kind %d at %d,%d rows %d..%d\n", w, s.kind, f.ox, f.oy, f.y0, f.y0 + f.rows); return false; };
+    if (s.npx != 4 || s.kind == kTileScatter || f.y0 < 0 || f.y0 + f.rows > sh_ || f.rows + 2 > kBoxMaxRows) return why("shape/rows");
+    std::vector<int> kid((size_t)f.rows, -1);
+    for (int r = 0; r < f.rows; r++) {
+      if (f.first[(size_t)r] < 0) continue;
+      // (the filter replicates the plane's left / right edge where the gather wraps: the runs of the plane's first and last
+      // dword column say so in their run words, and the kernel replaces the neighbour dword it would read across the edge)
+      kid[(size_t)r] = row_kid[(size_t)(f.y0 + r)];
+      if (kid[(size_t)r] < 0) return why("kid");
+    }
+    // R rows t = 0 .. rows + 1 <-> source row y0 - 1 + t; chunk columns relative to the R box origin (c0 - 1)
+    const int rrows = f.rows + 2;
+    std::vector<int> rfirst((size_t)rrows, -1), rlast((size_t)rrows, -1), alias((size_t)rrows);
+    for (int t = 0; t < rrows; t++) {
+      const int ys = f.y0 - 1 + t, yc = std::min(std::max(ys, 0), sh_ - 1);
+      alias[(size_t)t] = t + (yc - ys);  // BORDER_REPLICATE above / below the plane: the clamped row's staged bytes
+    }
+    for (int r = 0; r < f.rows; r++) {
+      if (f.first[(size_t)r] < 0) continue;
+      for (int t = r; t <= r + 2; t++) {
+        const int a = alias[(size_t)t];
+        const int lo = f.first[(size_t)r], hi = f.last[(size_t)r] + 2;  // [first - 1, last + 1] + 1
+        rfirst[(size_t)a] = rfirst[(size_t)a] < 0 ? lo : std::min(rfirst[(size_t)a], lo);
+        rlast[(size_t)a] = std::max(rlast[(size_t)a], hi);
+      }
+    }
+    std::vector<int> rpos((size_t)rrows, 0);
+    int rat = 0;
+    for (int t = 0; t < rrows; t++)
+      if (alias[(size_t)t] == t && rfirst[(size_t)t] >= 0) {
+        rpos[(size_t)t] = rat;
+        rat += rlast[(size_t)t] - rfirst[(size_t)t] + 1;
+      }
+    const int slot_pos = std::max(rat, f.npos);
+    if (rat <= 0 || slot_pos > max_pos_) return why("budget");
+    // runs: per B chunk column the maximal vertical spans of rows that hold it, cut where the kernel changes
+    struct Span { int c, r0, len, kid; };
+    std::vector<Span> spans;
+    for (int c = 0; c < f.ncols; c++) {
+      int r = 0;
+      while (r < f.rows) {
+        auto in = [&](int q) { return q < f.rows && f.first[(size_t)q] >= 0 && f.first[(size_t)q] <= c && c <= f.last[(size_t)q]; };
+        if (!in(r)) { r++; continue; }
+        int e = r + 1;
+        while (in(e) && kid[(size_t)e] == kid[(size_t)r]) e++;
+        spans.push_back({c, r, e - r, kid[(size_t)r]});
+        r = e;
+      }
+    }
+    std::stable_sort(spans.begin(), spans.end(), [](const Span& a, const Span& b) {
+      return a.kid != b.kid ? a.kid < b.kid : a.r0 != b.r0 ? a.r0 < b.r0 : a.c < b.c;
+    });
+    int ni = 0;
+    static const int min_ni = getenv("T360_PLAN_MIN_NI") ? atoi(getenv("T360_PLAN_MIN_NI")) : 1;
+    for (int cand = min_ni; cand <= kFusedMaxRun && ni == 0; cand++) {
+      int lanes = 0, in_kid = 0, prev = -1;
+      for (const Span& sp : spans) {
+        if (sp.kid != prev) lanes += (in_kid + 63) / 64 * 64, in_kid = 0, prev = sp.kid;
+        in_kid += 4 * ((sp.len + cand - 1) / cand);
+      }
+      lanes += (in_kid + 63) / 64 * 64;
+      if (lanes <= kFusedLanes) ni = cand;
+    }
+    if (ni == 0) return why("lanes");
+    if (dbg) {
+      std::set<int> ks_;
+      for (const Span& sp : spans) ks_.insert(sp.kid);
+      printf("fused ni %d kind %d pieces %d at %d,%d kids %d rows %d rat %d npos %d\n", ni, s.kind, (std::max(rat, f.npos) + 63) / 64, f.ox, f.oy, (int)ks_.size(), f.rows, rat, f.npos);
+    }
+
+    TileDesc t{};
+    t.ox = (int16_t)f.ox;
+    t.oy = (int16_t)f.oy;
+    t.kind = (int16_t)s.kind;
+    const bool partial = f.ox + s.w > dw_ || f.oy + s.h > dh_;
+    t.flags = (int16_t)(kTileFused | (partial ? kTilePartial : 0));
+    t.pieces = (int16_t)((slot_pos + kPieceChunks - 1) / kPieceChunks);
+    t.rows = (int16_t)f.rows;
+    t.fetched = rat;
+    t.pad[1] = ni;
+    t.pad[2] = f.npos;
+    const int mp = std::min(opt_.max_pieces, kMaxPieces);
+    const size_t cstride = (size_t)fused_chunk_dwords(mp), base = out->fchunks.size();
+    out->fchunks.resize(base + cstride, 0);
+    uint32_t* ct = &out->fchunks[base];
+    // R chunk table: rows are packed back to back, so the only positions without a chunk of their own lie behind the last row
+    uint32_t last_entry = 0;
+    for (int tr = 0; tr < rrows; tr++)
+      if (alias[(size_t)tr] == tr && rfirst[(size_t)tr] >= 0) {
+        const int sy = f.y0 - 1 + tr;
+        for (int c = rfirst[(size_t)tr]; c <= rlast[(size_t)tr]; c++) {
+          const int cx = wrap((f.c0 - 1 + c) * kStageChunk, sw_) / kStageChunk;
+          last_entry = ct[rpos[(size_t)tr] + c - rfirst[(size_t)tr]] = chunk_entry((uint32_t)sy, (uint32_t)cx);
+        }
+      }
+    for (int i = rat; i < mp * kPieceChunks; i++) ct[i] = last_entry;
+    uint32_t* btab = ct + (size_t)mp * kPieceChunks;
+    for (int r = 0; r < f.rows; r++) {
+      const uint32_t v = (uint32_t)(uint16_t)(int16_t)(f.first[(size_t)r] < 0 ? 0 : row_base(f, r));
+      btab[r / 2] |= v << (16 * (r & 1));
+    }
+    uint32_t* rtab = btab + 64;
+    for (int tr = 0; tr < rrows; tr++) {
+      const int a = alias[(size_t)tr];
+      const uint32_t v = (uint32_t)(uint16_t)(int16_t)(rfirst[(size_t)a] < 0 ? 0 : rpos[(size_t)a] - rfirst[(size_t)a]);
+      rtab[tr / 2] |= v << (16 * (tr & 1));
+    }
+    uint32_t* runs = rtab + 64;
+    uint32_t* winfo = runs + kFusedLanes;
+    std::fill(runs, runs + kFusedLanes, kRunDead);
+    {
+      int lane = 0, prev = -1, items = 0;
+      for (const Span& sp : spans) {
+        if (sp.kid != prev) {
+          lane = (lane + 63) / 64 * 64;
+          prev = sp.kid;
+        }
+        const int n = (sp.len + ni - 1) / ni;
+        for (int k = 0; k < n; k++) {
+          const int a = sp.r0 + (int)((int64_t)sp.len * k / n), b = sp.r0 + (int)((int64_t)sp.len * (k + 1) / n);
+          for (int j = 0; j < 4; j++, lane++) {
+            const int xabs = wrap((f.c0 + sp.c) * kStageChunk + 4 * j, sw_);
+            runs[lane] = (uint32_t)(sp.c * 4 + j) | ((uint32_t)a << 9) | ((uint32_t)(b - a) << 16) |
+                         (xabs == 0 ? kRunLeftEdge : 0u) | (xabs == sw_ - 4 ? kRunRightEdge : 0u);
+            winfo[lane / 64] = (uint32_t)sp.kid;
+          }
+          items += 4 * (b - a);
+        }
+      }
+      // lanes without a run of their own repeat the last run of their wave (a wave without any: the tile's last run and its
+      // kernel): identical dwords written twice, and no lane of the filter phase is ever predicated off
+      for (int w0 = 0; w0 < kFusedLanes; w0 += 64) {
+        uint32_t rep = kRunDead;
+        for (int l = w0; l < w0 + 64; l++)
+          if (runs[l] != kRunDead) rep = runs[l];
+        if (rep == kRunDead) {
+          rep = runs[lane - 1];
+          winfo[w0 / 64] = winfo[(lane - 1) / 64];
+        }
+        for (int l = w0; l < w0 + 64; l++)
+          if (runs[l] == kRunDead) runs[l] = rep;
+      }
+      winfo[8] = (uint32_t)ni;
+      out->stats.fused_blurred_bytes += (int64_t)items * 4;
+      out->stats.fused_run_slots += (int64_t)kFusedLanes * ni;
+    }
+    const size_t wstride = (size_t)tile_words(opt_.ks, opt_.waves), wb = out->ftlut.size();
+    out->ftlut.resize(wb + wstride, kWordDead);
+    pixel_words(f, &out->ftlut[wb]);
+    out->ftiles.push_back(t);
+    out->stats.n_fused++;
+    out->stats.fused_raw_bytes += (int64_t)rat * kStageChunk;
+    return true;
+  }
+
   void emit(Foot& f, HostGatherPlan* out, std::vector<TileDesc>* direct) const {
     choose_skew(&f);
+    if (fuse_on()) {
+      if (f.feasible && emit_fused(f, out)) return;
+      mark_needed(f, !f.feasible, out);
+    }
     TileDesc t{};
     t.ox = (int16_t)f.ox;
     t.oy = (int16_t)f.oy;
@@ -438,21 +661,9 @@ class Planner {
       for (size_t q = 0; q < f.blocks.size(); q++) out->chunks[base + (size_t)mp * kPieceChunks + 64 + q] = f.blocks[q];
     // pixel words at a fixed stride, lane order of the gather; 16x16 tiles of a mixed plan use the first word of a uint4
     const int wstride = tile_words(opt_.ks, opt_.waves);
-    const int per_lane = opt_.ks == 8 ? 1 : 4;
     const size_t wb = out->tlut.size();
     out->tlut.resize(wb + (size_t)wstride, kWordDead);
-    uint32_t* w = &out->tlut[wb];
-    for (int tid = 0; tid < s.lanes; tid++)
-      for (int p = 0; p < s.npx; p++) {
-        int px, py;
-        if (!pixel_of_lane(f, tid, p, &px, &py)) continue;
-        const LutEntry& e = lut_[(size_t)py * dw_ + px];
-        int sx = e.ix;
-        if (f.seam && sx >= (sw_ >> 1)) sx -= sw_;
-        const uint32_t xrel = (uint32_t)(sx - lo_ - f.c0 * kStageChunk);
-        const uint32_t r0 = (uint32_t)(e.iy - lo_ - f.y0);
-        w[tid * per_lane + p] = xrel | (r0 << kWordRowShift) | ((uint32_t)e.frac << kWordFracShift);
-      }
+    pixel_words(f, &out->tlut[wb]);
     out->tiles.push_back(t);
     st.fetched_bytes += (int64_t)f.fetched * kStageChunk;
     if (opt_.model_stats) {
@@ -794,6 +1005,43 @@ class Planner {
       a.lds_cycles_model += b.lds_cycles_model;
       a.line_bytes += b.line_bytes;
       for (int i = 0; i < 33; i++) a.pieces_hist[i] += b.pieces_hist[i];
+      a.n_fused += b.n_fused; a.fused_raw_bytes += b.fused_raw_bytes; a.fused_blurred_bytes += b.fused_blurred_bytes;
+      a.fused_run_slots += b.fused_run_slots;
+    }
+    if (fuse_on()) {
+      // the fused work list, in the same execution order as the unfused one (Z-order of 64x16 cells), and the segments the
+      // unfused tiles still need
+      out->seg_needed.assign(opt_.fuse->segs.size(), 0);
+      std::vector<std::pair<uint32_t, uint32_t>> fw;
+      for (size_t ti = 0; ti < nthreads; ti++) {
+        for (size_t k = 0; k < part[ti].ftiles.size(); k++) fw.push_back({(uint32_t)ti, (uint32_t)k});
+        for (size_t i = 0; i < part[ti].seg_needed.size(); i++) out->seg_needed[i] |= part[ti].seg_needed[i];
+      }
+      auto fmorton = [](unsigned x, unsigned y) {
+        uint64_t m = 0;
+        for (int b = 0; b < 16; b++) m |= ((uint64_t)((x >> b) & 1) << (2 * b)) | ((uint64_t)((y >> b) & 1) << (2 * b + 1));
+        return m;
+      };
+      std::vector<uint64_t> fkey(fw.size());
+      std::vector<size_t> fidx(fw.size());
+      for (size_t i = 0; i < fw.size(); i++) {
+        const TileDesc& t = part[fw[i].first].ftiles[fw[i].second];
+        fkey[i] = ((opt_.order == 2 ? fmorton((unsigned)t.ox >> 6, (unsigned)t.oy >> 4) : 0) << 32) | ((uint64_t)(uint16_t)t.oy << 16) | (uint16_t)t.ox;
+        fidx[i] = i;
+      }
+      if (opt_.order != 0) std::stable_sort(fidx.begin(), fidx.end(), [&](size_t a, size_t b) { return fkey[a] < fkey[b]; });
+      const size_t fws = (size_t)tile_words(opt_.ks, opt_.waves), fcs = (size_t)fused_chunk_dwords(std::min(opt_.max_pieces, kMaxPieces));
+      out->ftiles.assign(fw.size(), TileDesc{});
+      out->ftlut.assign(fw.size() * fws, 0u);
+      out->fchunks.assign(fw.size() * fcs, 0u);
+      for (size_t i = 0; i < fw.size(); i++) {
+        const HostGatherPlan& p = part[fw[fidx[i]].first];
+        const size_t k = fw[fidx[i]].second;
+        out->ftiles[i] = p.ftiles[k];
+        memcpy(&out->ftlut[i * fws], &p.ftlut[k * fws], fws * sizeof(uint32_t));
+        memcpy(&out->fchunks[i * fcs], &p.fchunks[k * fcs], fcs * sizeof(uint32_t));
+      }
+      out->nftiles = (int)fw.size();
     }
     const size_t nt = where.size();
     std::vector<size_t> idx(nt);
@@ -871,6 +1119,7 @@ class Planner {
   int dw_, dh_, sw_, sh_;
   PlanOptions opt_;
   int lo_, hi_, max_pos_;
+  std::vector<std::vector<int>> row_segs_;  // fuse_on(): segments intersecting each source row
 };
 
 }  // namespace

@@ -12,6 +12,18 @@
 
 namespace t360 {
 
+// What the planner needs to know about a plane's segmented low-pass to FUSE it into the gather (t360_internal.h "fused
+// low-pass tiles"; MONO inputs only).  row_kid[y] = index of the (fusable) kernel every pixel of source row y is filtered
+// with, or -1 (the row's segments have different or unfusable kernels, or do not cover it); segs = the segment
+// rectangles, for the list of segments some UNFUSED tile still reads blurred pixels of.
+struct FuseSegment {
+  int left, top, width, height;
+};
+struct FuseInfo {
+  std::vector<int16_t> row_kid;
+  std::vector<FuseSegment> segs;
+};
+
 struct PlanOptions {
   int ks = 4;            // taps per axis of the interpolation: 1, 2, 4, 8
   int waves = 4;         // waves per workgroup of the gather kernel: 4, or 8 (then 128x16 tiles of 512 lanes exist)
@@ -33,6 +45,8 @@ struct PlanOptions {
   bool model_dual = false;   // bank model of ds_read_b64 on two copies instead of two ds_read_b32 on one
   int model_b_shift = 0;     // extra byte offset of copy B in the bank model (tests/plan_sim.py)
   bool model_stats = false;  // fill PlanStats::lds_cycles_model (tests/plan_sim.py)
+  const FuseInfo* fuse = nullptr;  // != nullptr (workgroups of 8 waves, bilinear / bicubic): tiles that can filter their own
+                                   // footprint go to the fused work list (HostGatherPlan::f*)
 };
 
 struct PlanStats {
@@ -43,6 +57,10 @@ struct PlanStats {
   int64_t line_bytes = 0;      // model_stats: bytes of the distinct 128-byte lines each tile touches, summed
   int64_t lds_cycles_model = 0;  // modelled ds_read_b64 LDS cycles (32-lane groups x stencil rows), summed over the tiles
   int pieces_hist[33] = {0};   // staged tiles per size (1 KiB pieces per copy)
+  int n_fused = 0;             // fused low-pass tiles (their bytes are NOT in the sums above)
+  int64_t fused_raw_bytes = 0;      // raw (dilated) chunks fused tiles stage per frame x 16
+  int64_t fused_blurred_bytes = 0;  // blurred dwords they compute per frame x 4
+  int64_t fused_run_slots = 0;      // lanes x longest run, summed (occupancy of the filter phase = blurred / 4 / this)
 };
 
 struct HostGatherPlan {
@@ -51,6 +69,12 @@ struct HostGatherPlan {
   std::vector<uint32_t> tlut;     // pixel words, lane order (tile_word())
   std::vector<uint32_t> chunks;   // per staged tile 64 * pieces entries: chunk_entry()
   bool scatter = false;           // the chunk tables carry 128 block origins per tile (tile_chunk_dwords(.., true))
+  // fused low-pass tiles (PlanOptions::fuse), a work list of their own in execution order: descriptors, pixel words at the
+  // stride of the unfused list, tables at fused_chunk_dwords(max_pieces)
+  std::vector<TileDesc> ftiles;
+  std::vector<uint32_t> ftlut, fchunks;
+  int nftiles = 0;
+  std::vector<uint8_t> seg_needed;  // per FuseInfo segment: an unfused (staged or direct) tile reads its blurred pixels
   PlanStats stats;
 };
 

@@ -942,6 +942,276 @@ hipError_t launch_ks(const TiledArgs& a, int groups, hipStream_t stream) {
   return hipErrorInvalidValue;
 }
 
+
+// ============================ fused low-pass tiles ==============================================
+// remap_fused_kernel: the tiled gather with the segmented low-pass of its own footprint done in LDS (t360_internal.h
+// "fused low-pass tiles"; reference filterPlane -> filterSegment -> cv::sepFilter2D feeding cv::remap on ONE plane,
+// VideoFrameTransform.cpp:727-733 + :748-754, :173-204).  What changes against tile_waves():
+//   * the DMA stages the RAW footprint R, dilated by the kernel radius (one 16-byte chunk left and right, one row above and
+//     below, clamped at the plane's top and bottom: BORDER_REPLICATE);
+//   * every lane owns one vertical RUN of <= kFusedMaxRun blurred dwords (4 px each) of one dword column: per R row of the
+//     run it reads the three aligned dwords around its column, takes the row pass of its 4 pixels as v_dot4_u32_u8 against
+//     the byte-shifted tap variants (SGPRs: a wave's runs share one kernel), keeps the last three row results in registers
+//     and takes the column pass as v_mad_u32_u24 -- the arithmetic of lowpass_q8w_rows(), bit for bit;
+//   * the blurred dwords are written IN PLACE into the same ring slot at the B positions (the layout the gather's pixel
+//     words address) after a second barrier: every R byte of the slot has been read by then;
+//   * the gather runs one frame behind the filter, so the frame loop is
+//       wait DMA(i) | BARRIER | gather B(i-1) | filter R(i) into registers | BARRIER | store(i-1), write B(i), DMA(i+K-1).
+#ifndef T360_FUSED_GROUP
+#define T360_FUSED_GROUP 2
+#endif
+struct FusedFetch {
+  uint32_t rowdw_r;  // dword `lane` of the R row table
+  uint32_t run;      // this lane's run word
+  uint32_t kid;      // kernel index of this wave's runs
+  uint32_t ni;       // longest run of the tile
+};
+
+template <int KS, int P, int K>
+__device__ __forceinline__ void fused_waves(const TiledArgs& a, const TiledPlane& pl, const uint32_t* __restrict__ taps,
+                                            const TileDesc& t, const TileFetch& tf, const FusedFetch& ff,
+                                            const uint8_t* __restrict__ lds, int f0, int f1) {
+  // (GROUP = 2: two pixels' stencil reads in flight at a time instead of all four -- 16 registers the filter phase's
+  // addresses and row window need; the frame's LDS round trips are dominated by the filter's row steps anyway)
+  constexpr int WAVES = 8, NPX = 4, GROUP = T360_FUSED_GROUP;
+  using R = Slot<P, false>;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mine = ((int)t.pieces - wave + WAVES - 1) / WAVES;
+  const bool has_px = t.kind == kTileWide128 || wave < 4;
+  int goff[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int j = 3 - k;
+    const uint32_t e = tf.chunk[j];
+    goff[k] = (j < mine && WAVES * j < P) ? (int)(e >> 12) * pl.sstride + (int)(e & 4095u) * kStageChunk : 0;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds + (uint32_t)wave * 1024u;
+  auto issue = [&](int f, int slot_bytes) {
+    if (mine <= 0) return;
+    const uint8_t* base = pl.src + (size_t)f * pl.src_frame_bytes;
+    dma_frame_4(mine, base, lds_base + (uint32_t)slot_bytes, WAVES * 1024u, goff);
+  };
+  const int per_frame = mine;
+  const int nf = f1 - f0;
+#pragma unroll
+  for (int j = 0; j < K - 1; j++)
+    if (j < nf) issue(f0 + j, j * R::kSlot);
+  PixelSetup<NPX, KS> px;
+  load_pixels<NPX, KS, P>(tf, a.wpack, px);
+  // ---- the lane's run: LDS addresses (inside a slot) of its R rows and of the B dwords it writes, two per register ----
+  const uint32_t rw = ff.run;
+  const int run_len = (int)((rw >> 16) & 15u);  // >= 1: a plan has no idle lanes (t360_internal.h)
+  const int dcol = (int)(rw & 511u), r0 = (int)((rw >> 9) & 127u);
+  const int ni = __builtin_amdgcn_readfirstlane((int)ff.ni);
+  constexpr int NR = kFusedMaxRun + 2;
+  uint32_t raddr2[NR / 2], baddr2[kFusedMaxRun / 2];
+#pragma unroll
+  for (int i = 0; i < NR; i += 2) {
+    // R row t of the tile is source row y0 - 1 + t; the R box starts one chunk left of the B box: byte 4 * dcol of the B box is
+    // byte 16 + 4 * dcol of the R box, and the 12-byte window starts 4 bytes left of it
+    const int a0 = row_base_of(ff.rowdw_r, (r0 + i) & (kBoxMaxRows - 1)) * kStageChunk + 12 + 4 * dcol;
+    const int a1 = row_base_of(ff.rowdw_r, (r0 + i + 1) & (kBoxMaxRows - 1)) * kStageChunk + 12 + 4 * dcol;
+    raddr2[i / 2] = i < ni + 2 ? ((uint32_t)a0 & 0xffffu) | ((uint32_t)a1 << 16) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kFusedMaxRun; j += 2) {
+    // slots of the run beyond its length aim at its LAST dword: the dwords are written in descending order, so whatever a
+    // shorter run computes out of rows that are not its own is overwritten by the real thing (one lane's LDS stores are
+    // executed in order) -- no per-lane predicate anywhere in the filter phase
+    const int b0 = row_base_of(tf.rowdw, (r0 + min(j, run_len - 1)) & (kBoxMaxRows - 1)) * kStageChunk + 4 * dcol;
+    const int b1 = row_base_of(tf.rowdw, (r0 + min(j + 1, run_len - 1)) & (kBoxMaxRows - 1)) * kStageChunk + 4 * dcol;
+    baddr2[j / 2] = j < ni ? ((uint32_t)b0 & 0xffffu) | ((uint32_t)b1 << 16) : 0u;
+  }
+  // the wave's kernel: 10 horizontal tap dwords + 3 vertical taps, scalar
+  uint32_t tp[13];
+  {
+    const uint32_t* __restrict__ q = taps + (size_t)__builtin_amdgcn_readfirstlane((int)ff.kid) * kFusedTapDwords;
+#pragma unroll
+    for (int k = 0; k < 13; k++) tp[k] = __builtin_amdgcn_readfirstlane((int)q[k]);
+  }
+  pin_pixels<NPX, KS>(px);
+#pragma unroll
+  for (int i = 0; i < NR / 2; i++) asm volatile("" : "+v"(raddr2[i]));
+#pragma unroll
+  for (int j = 0; j < kFusedMaxRun / 2; j++) asm volatile("" : "+v"(baddr2[j]));
+  const bool edge_l = (rw & kRunLeftEdge) != 0, edge_r = (rw & kRunRightEdge) != 0;
+  const bool any_edge = __builtin_amdgcn_readfirstlane((int)(__ballot(edge_l || edge_r) != 0ull)) != 0;
+
+  const bool dword_store = !(t.flags & kTilePartial) && pl.dst_dword_ok;
+  const uint32_t doff = out_pos<NPX>(pl, t, dword_store, 0u);
+  uint8_t* __restrict__ d = uniform_ptr(pl.dst + (size_t)f0 * pl.dst_frame_bytes);
+  uint32_t pending = 0;
+  uint32_t half = 1u << 15;
+  asm volatile("" : "+v"(half));
+
+  // one frame's filter pass out of the slot at byte SLOT: blurred dwords of the run into bl[]
+  uint32_t bl[kFusedMaxRun];
+  auto filter = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    uint32_t res[3][4];
+    // (plain loads: hipcc counts them itself, so it may keep the next row in flight while this one is consumed.  With asm
+    // loads it could not be kept from COPYING a destination register before the s_waitcnt that covers it -- the row steps
+    // are separate basic blocks, and the copies appear where they merge)
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      if (i < ni + 2) {  // wave-uniform
+        const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(
+            lds + SLOT + ((i & 1) ? (raddr2[i / 2] >> 16) : (raddr2[i / 2] & 0xffffu)));
+        uint32_t D0 = q[0], D1 = q[1], D2 = q[2];
+        if (any_edge) {
+          if (edge_l) D0 = (D1 & 0xffu) * 0x01010101u;
+          if (edge_r) D2 = (D1 >> 24) * 0x01010101u;
+        }
+        uint32_t* r = res[i % 3];
+        r[0] = __builtin_amdgcn_udot4(D1, tp[1], __builtin_amdgcn_udot4(D0, tp[0], 0u, false), false);
+        r[1] = __builtin_amdgcn_udot4(D2, tp[4], __builtin_amdgcn_udot4(D1, tp[3], __builtin_amdgcn_udot4(D0, tp[2], 0u, false), false), false);
+        r[2] = __builtin_amdgcn_udot4(D2, tp[7], __builtin_amdgcn_udot4(D1, tp[6], __builtin_amdgcn_udot4(D0, tp[5], 0u, false), false), false);
+        r[3] = __builtin_amdgcn_udot4(D2, tp[9], __builtin_amdgcn_udot4(D1, tp[8], 0u, false), false);
+        if (i >= 2) {
+          uint32_t c[4];
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            c[p] = half;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+              const uint32_t kyk = tp[10 + k], rv = res[(i - 2 + k) % 3][p], cv = c[p];
+              uint32_t nv;
+              asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(nv) : "s"(kyk), "v"(rv), "v"(cv));
+              c[p] = nv;
+            }
+          }
+          const uint32_t lo = sat_pk_u8(__builtin_amdgcn_perm(c[1], c[0], 0x07060302u));
+          const uint32_t hi = sat_pk_u8(__builtin_amdgcn_perm(c[3], c[2], 0x07060302u));
+          bl[i - 2] = lo | (hi << 16);
+        }
+      }
+    }
+  };
+  auto write_blurred = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+    for (int j = kFusedMaxRun - 1; j >= 0; j--)
+      if (j < ni) {  // wave-uniform
+        *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + SLOT + ((j & 1) ? (baddr2[j / 2] >> 16) : (baddr2[j / 2] & 0xffffu))) = bl[j];
+      }
+  };
+
+  for (int i = 0; i <= nf; i += K) {
+#define T360_FSTEP(S)                                                                                          \
+    if constexpr (S < K) if (i + S <= nf) {                                                                    \
+      constexpr int SP = (S + K - 1) % K; /* the slot of the previous frame */                                 \
+      const int fr = i + S;               /* frame filtered in this step; the gather handles frame fr - 1 */   \
+      if (fr < nf) wait_vmcnt(min(K - 2, nf - 1 - fr) * per_frame);                                            \
+      frame_barrier(); /* R(fr) is complete in slot S, B(fr - 1) in slot SP */                                 \
+      if (fr > 0 && has_px) pending = gather<NPX, KS, GROUP, SP * R::kSlot>(px, lds, dword_store);             \
+      asm volatile("" : "+v"(pending));                                                                        \
+      if (fr < nf) filter(std::integral_constant<int, S * R::kSlot>{});                                        \
+      frame_barrier(); /* every read of slot S (R) and of slot SP (B) is done */                               \
+      if (fr > 0) {                                                                                            \
+        if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store, true);                        \
+        d += pl.dst_frame_bytes;                                                                               \
+      }                                                                                                        \
+      if (fr < nf) write_blurred(std::integral_constant<int, S * R::kSlot>{});                                 \
+      if (fr + K - 1 < nf) issue(f0 + fr + K - 1, SP * R::kSlot);                                              \
+    }
+    T360_FSTEP(0) T360_FSTEP(1) T360_FSTEP(2)
+#undef T360_FSTEP
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void remap_fused_kernel(FusedArgs fa) {
+  constexpr int RINGKB = 76, WAVES = 8;
+  const TiledArgs& a = fa.base;
+  extern __shared__ __attribute__((aligned(64))) uint8_t lds[];
+  // the XCD-aware work item order of remap_tiled_kernel (no direct tiles in this list)
+  int id = blockIdx.x, b, g, f0, f1;
+  TiledPlane pl = a.plane[0];
+  const uint32_t* taps = fa.taps[0];
+  {
+    const int xcd = id & 7, k = id >> 3;
+    const int q = a.total_tiles >> 3, rem = a.total_tiles & 7;
+    const int len = q + (xcd < rem ? 1 : 0), start = xcd * q + (xcd < rem ? xcd : rem);
+    const int len_tail = (len * a.tail_percent) / 100, len_head = len - len_tail;
+    int fpb;
+    if (k < len_head * a.groups) {
+      const int t_local = k / a.groups;
+      b = start + t_local;
+      g = k - t_local * a.groups;
+      fpb = a.frames_per_block;
+    } else {
+      const int k2 = k - len_head * a.groups;
+      const int t_local = k2 / a.tail_groups;
+      if (t_local >= len_tail) return;
+      b = start + len_head + t_local;
+      g = k2 - t_local * a.tail_groups;
+      fpb = a.tail_frames;
+    }
+    f0 = g * fpb;
+    f1 = min(f0 + fpb, a.nframes);
+  }
+  if (a.nplanes > 1 && b >= pl.ntiles) {
+    b -= pl.ntiles;
+    pl = a.plane[1];
+    taps = fa.taps[1];
+    if (a.nplanes > 2 && b >= pl.ntiles) {
+      b -= pl.ntiles;
+      pl = a.plane[2];
+      taps = fa.taps[2];
+      if (a.nplanes > 3 && b >= pl.ntiles) {
+        b -= pl.ntiles;
+        pl = a.plane[3];
+        taps = fa.taps[3];
+      }
+    }
+  }
+  // per-tile tables: pixel words, R chunk entries, B row table (as in an unfused plan), then the R row table, the run words
+  // and the wave info
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TileFetch tf;
+  FusedFetch ff;
+  {
+    const uint4 v = reinterpret_cast<const uint4*>(pl.tlut + (size_t)b * tile_words(KS, WAVES))[tid];
+    tf.words[0] = v.x; tf.words[1] = v.y; tf.words[2] = v.z; tf.words[3] = v.w;
+    const uint32_t* __restrict__ tc = pl.chunks + (size_t)b * fused_chunk_dwords(a.max_pieces);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int piece = wave + WAVES * j;
+      tf.chunk[j] = piece < a.max_pieces ? tc[piece * kPieceChunks + lane] : 0u;
+    }
+    const uint32_t* __restrict__ tb = tc + a.max_pieces * kPieceChunks;
+    tf.rowdw = tb[lane];
+    tf.origin = 0u;
+    ff.rowdw_r = tb[64 + lane];
+    ff.run = tb[128 + tid];
+    ff.kid = tb[128 + kFusedLanes + wave];
+    ff.ni = tb[128 + kFusedLanes + 8];
+  }
+  const TileDesc t = pl.tiles[b];
+  const int pieces = (int)t.pieces;
+#define T360_FTILE(P) \
+  if constexpr (Cls<RINGKB, P, false>::K >= 2) fused_waves<KS, P, Cls<RINGKB, P, false>::K>(a, pl, taps, t, tf, ff, lds, f0, f1);
+  T360_FOR_CLASS(pieces, T360_FTILE)
+#undef T360_FTILE
+}
+
+template <int KS>
+hipError_t launch_fused_ks(const FusedArgs& fa, hipStream_t stream) {
+  constexpr int lds_bytes = 76 * 1024;
+  const TiledArgs& a = fa.base;
+  if (a.max_pieces > max_pieces_of<76, false>()) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(remap_fused_kernel<KS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  const int groups = (a.nframes + a.frames_per_block - 1) / a.frames_per_block;
+  const int per_xcd = (a.total_tiles + 7) / 8;
+  const int tail = (per_xcd * a.tail_percent) / 100;
+  const int items = (per_xcd - tail) * groups + (tail + 1) * a.tail_groups;
+  hipLaunchKernelGGL((remap_fused_kernel<KS>), dim3(8 * items, 1, 1), dim3(512), (size_t)lds_bytes, stream, fa);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 const char* remap_tiled_kernel_name(int ks, int ring_kb, int waves) {
@@ -958,6 +1228,17 @@ hipError_t launch_remap_tiled(const TiledArgs& a, hipStream_t stream) {
     case 2: return launch_ks<2>(a, groups, stream);
     case 4: return launch_ks<4>(a, groups, stream);
     case 8: return launch_ks<8>(a, groups, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_remap_fused(const FusedArgs& fa, hipStream_t stream) {
+  const TiledArgs& a = fa.base;
+  if (a.total_tiles <= 0 || a.nframes <= 0) return hipSuccess;
+  if (a.waves != 8 || a.ring_kb != 76 || a.total_direct != 0) return hipErrorInvalidValue;
+  switch (a.ks) {
+    case 2: return launch_fused_ks<2>(fa, stream);
+    case 4: return launch_fused_ks<4>(fa, stream);
     default: return hipErrorInvalidValue;
   }
 }

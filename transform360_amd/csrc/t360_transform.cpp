@@ -208,6 +208,7 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
   if (getenv("T360_NO_WIDE_LOWPASS")) use_wide_lowpass_ = false;
   if (getenv("T360_NO_MERGED_LOWPASS")) merge_lowpass_ = false;
+  if (getenv("T360_NO_FUSED_LOWPASS")) fuse_lowpass_ = false;
 #endif
   ok_ = true;
 }
@@ -575,8 +576,9 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
   p.out_h = outputHeight;
   p.map_w = P.map_w;
   p.map_h = P.map_h;
-  p.tiles_w = p.tiles_h = -1;
-  p.ntiles = 0;
+  p.lp.tiles_w = p.lp.tiles_h = p.lp_part.tiles_w = p.lp_part.tiles_h = -1;
+  p.lp.ntiles = p.lp_part.ntiles = 0;
+  p.fuse_ok = false;
   p.filter.segments.clear();
 
   if (ctx_.enable_low_pass_filter) {
@@ -650,6 +652,16 @@ bool VideoFrameTransform::generateMapForPlane(int inputWidth, int inputHeight, i
                                 hipMemcpyHostToDevice, stream_), "hipMemcpy(taps)") ||
           !check(hipMemcpyAsync(p.taps_f32.as<void>(), f32.data(), f32.size() * sizeof(float),
                                 hipMemcpyHostToDevice, stream_), "hipMemcpy(taps)"))
+        return false;
+    }
+    // fused low-pass tiles: the kernels a gather tile can apply to its own footprint, and which source rows they cover
+    std::vector<uint32_t> ftaps;
+    p.fuse_ok = fuse_lowpass_ && build_fuse_info(ctx_, p.filter, inputWidth, inputHeight, &p.fuse_info, &ftaps);
+    if (p.fuse_ok) {
+      if (!p.fuse_taps.reserve(ftaps.size() * sizeof(uint32_t))) return check(hipErrorOutOfMemory, "hipMalloc(fused taps)");
+      if (!check(hipMemcpyAsync(p.fuse_taps.as<void>(), ftaps.data(), ftaps.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                stream_), "hipMemcpy(fused taps)") ||
+          !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
         return false;
     }
   }
@@ -768,10 +780,14 @@ static bool same_run(const t360::Segment& a, const t360::Segment& b) {
 
 // Tile work list of the low-pass for a plane of w x h (reference filterPlane's segment loop,
 // VideoFrameTransform.cpp:630-691: every segment once per eye).
-bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex) {
-  if (p.tiles_w == w && p.tiles_h == h) return true;
+bool VideoFrameTransform::ensureTiles(PlaneState& p, PlaneState::LowpassLists& l, const std::vector<uint8_t>* needed, int w, int h,
+                                      int imagePlaneIndex) {
+  // `needed` (one flag per segment, MONO inputs) restricts the lists to the segments some unfused gather tile still reads;
+  // a handle's needed set belongs to its long-batch plan and never changes between calls
+  if (l.tiles_w == w && l.tiles_h == h) return true;
+  auto wanted = [&](size_t i) { return needed == nullptr || (i < needed->size() && (*needed)[i]); };
   // the lists are about to be rewritten in place: a call still running on another pipeline lane may be reading them
-  if (p.tiles_w >= 0 && !quiesceLanes()) return false;
+  if (l.tiles_w >= 0 && !quiesceLanes()) return false;
   std::vector<LowpassTile> tiles, fast_tiles, rest_tiles, wide_tiles;
   int max_rows_rest = 0, fast_lds = 0, wide_lds = 0;
   int ox[2] = {0, 0}, oy[2] = {0, 0}, eyes = 1;
@@ -787,6 +803,7 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
   for (int e = 0; e < eyes; e++)
     for (size_t i = 0; i < p.filter.segments.size(); i++) {
       const Segment& s = p.filter.segments[i];
+      if (!wanted(i)) continue;
       const int L = s.left + ox[e], T = s.top + oy[e];
       if (L < 0 || T < 0 || s.width < 0 || s.height < 0 || L + s.width > w || T + s.height > h) {
         // cv::Mat::operator()(Rect) throws; filterSegment prints and carries on (:198-203)
@@ -824,13 +841,13 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
         // the result does not depend on where the ROI borders are.  Runs are cut into tiles of
         // <= 128 x 128 px: 8 row groups of 32 lanes x 4 px per workgroup.
         const size_t n = p.filter.segments.size();
-        const bool continues_prev = i > 0 && p.seg_fast[i - 1] && same_run(p.filter.segments[i - 1], s);
+        const bool continues_prev = i > 0 && wanted(i - 1) && p.seg_fast[i - 1] && same_run(p.filter.segments[i - 1], s);
         if (!continues_prev) {
           // the run = this segment and the members that follow it AND still fit the plane (a plane smaller than the one
           // the segments were computed for -- the filter's alpha-plane quirk -- keeps the members that fit, like the
           // reference, which range-checks every segment on its own)
           int run_w = s.width;
-          for (size_t k = i + 1; k < n && p.seg_fast[k] && same_run(p.filter.segments[k - 1], p.filter.segments[k]) &&
+          for (size_t k = i + 1; k < n && wanted(k) && p.seg_fast[k] && same_run(p.filter.segments[k - 1], p.filter.segments[k]) &&
                                  L + run_w + p.filter.segments[k].width <= w;
                k++)
             run_w += p.filter.segments[k].width;
@@ -867,48 +884,50 @@ bool VideoFrameTransform::ensureTiles(PlaneState& p, int w, int h, int imagePlan
         }
       }
     }
-  p.ntiles = (int)tiles.size();
-  p.max_rows = max_rows;
-  p.full_cover = covered == (int64_t)w * h;  // segments of one plane never overlap
-  if (p.ntiles) {
-    if (!p.tiles.reserve(tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
-    if (!check(hipMemcpyAsync(p.tiles.as<void>(), tiles.data(), tiles.size() * sizeof(LowpassTile),
+  l.ntiles = (int)tiles.size();
+  l.max_rows = max_rows;
+  // (segments of one plane never overlap; a partial list exists only for planes their segments cover, and nobody reads
+  // what it leaves out)
+  l.full_cover = needed != nullptr || covered == (int64_t)w * h;
+  if (l.ntiles) {
+    if (!l.tiles.reserve(tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(l.tiles.as<void>(), tiles.data(), tiles.size() * sizeof(LowpassTile),
                               hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)") ||
         !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
       return false;
   }
-  p.nfast = (int)fast_tiles.size();
-  p.nrest = (int)rest_tiles.size();
-  p.max_rows_rest = max_rows_rest;
-  p.fast_lds_bytes = fast_lds;
-  p.nwide = (int)wide_tiles.size();
-  p.wide_lds_bytes = wide_lds;
-  if (p.nwide) {
-    if (!p.tiles_wide.reserve(wide_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
-    if (!check(hipMemcpyAsync(p.tiles_wide.as<void>(), wide_tiles.data(), wide_tiles.size() * sizeof(LowpassTile),
+  l.nfast = (int)fast_tiles.size();
+  l.nrest = (int)rest_tiles.size();
+  l.max_rows_rest = max_rows_rest;
+  l.fast_lds_bytes = fast_lds;
+  l.nwide = (int)wide_tiles.size();
+  l.wide_lds_bytes = wide_lds;
+  if (l.nwide) {
+    if (!l.tiles_wide.reserve(wide_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(l.tiles_wide.as<void>(), wide_tiles.data(), wide_tiles.size() * sizeof(LowpassTile),
                               hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
       return false;
   }
-  if (p.nfast) {
-    if (!p.tiles_fast.reserve(fast_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
-    if (!check(hipMemcpyAsync(p.tiles_fast.as<void>(), fast_tiles.data(), fast_tiles.size() * sizeof(LowpassTile),
+  if (l.nfast) {
+    if (!l.tiles_fast.reserve(fast_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(l.tiles_fast.as<void>(), fast_tiles.data(), fast_tiles.size() * sizeof(LowpassTile),
                               hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
       return false;
   }
-  if (p.nrest) {
-    if (!p.tiles_rest.reserve(rest_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
-    if (!check(hipMemcpyAsync(p.tiles_rest.as<void>(), rest_tiles.data(), rest_tiles.size() * sizeof(LowpassTile),
+  if (l.nrest) {
+    if (!l.tiles_rest.reserve(rest_tiles.size() * sizeof(LowpassTile))) return check(hipErrorOutOfMemory, "hipMalloc(tiles)");
+    if (!check(hipMemcpyAsync(l.tiles_rest.as<void>(), rest_tiles.data(), rest_tiles.size() * sizeof(LowpassTile),
                               hipMemcpyHostToDevice, stream_), "hipMemcpy(tiles)"))
       return false;
   }
   if (!check(hipStreamSynchronize(stream_), "hipStreamSynchronize")) return false;
-  p.tiles_w = w;
-  p.tiles_h = h;
+  l.tiles_w = w;
+  l.tiles_h = h;
   return true;
 }
 
 // launch arguments of the low-pass of one plane (after ensureTiles)
-void VideoFrameTransform::fillLowpassArgs(const PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
+void VideoFrameTransform::fillLowpassArgs(const PlaneState& p, const PlaneState::LowpassLists& l, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                                           uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h,
                                           t360::LowpassArgs* out) const {
   LowpassArgs a;
@@ -927,18 +946,18 @@ void VideoFrameTransform::fillLowpassArgs(const PlaneState& p, const uint8_t* d_
   a.tile_w = kTileW;
   a.dst_dword_ok = ((uintptr_t)d_out % 4 == 0 && out_stride % 4 == 0 && out_frame_bytes % 4 == 0) ? 1 : 0;
   const bool src_dword_ok = (uintptr_t)d_in % 4 == 0 && in_stride % 4 == 0 && in_frame_bytes % 4 == 0 && w % 4 == 0 && w >= 4;
-  if ((p.nfast > 0 || p.nwide > 0) && src_dword_ok) {
-    a.wide_tiles = p.tiles_wide.as<LowpassTile>();
-    a.nwide = p.nwide;
-    a.wide_lds_bytes = p.wide_lds_bytes;
+  if ((l.nfast > 0 || l.nwide > 0) && src_dword_ok) {
+    a.wide_tiles = l.tiles_wide.as<LowpassTile>();
+    a.nwide = l.nwide;
+    a.wide_lds_bytes = l.wide_lds_bytes;
     a.taps_sh = p.taps_sh.as<uint32_t>();
-    a.fast_tiles = p.tiles_fast.as<LowpassTile>();
-    a.nfast = p.nfast;
+    a.fast_tiles = l.tiles_fast.as<LowpassTile>();
+    a.nfast = l.nfast;
     a.fast_ky = p.fast_ky;
-    a.fast_lds_bytes = p.fast_lds_bytes;
-    a.tiles = p.tiles_rest.as<LowpassTile>();
-    a.ntiles = p.nrest;
-    a.max_rows = p.max_rows_rest;
+    a.fast_lds_bytes = l.fast_lds_bytes;
+    a.tiles = l.tiles_rest.as<LowpassTile>();
+    a.ntiles = l.nrest;
+    a.max_rows = l.max_rows_rest;
   } else {
     a.wide_tiles = nullptr;
     a.nwide = 0;
@@ -948,19 +967,20 @@ void VideoFrameTransform::fillLowpassArgs(const PlaneState& p, const uint8_t* d_
     a.nfast = 0;
     a.fast_ky = 0;
     a.fast_lds_bytes = 0;
-    a.tiles = p.tiles.as<LowpassTile>();
-    a.ntiles = p.ntiles;
-    a.max_rows = p.max_rows;
+    a.tiles = l.tiles.as<LowpassTile>();
+    a.ntiles = l.ntiles;
+    a.max_rows = l.max_rows;
   }
   *out = a;
 }
 
-bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes,
+bool VideoFrameTransform::runLowpass(PlaneState& p, PlaneState::LowpassLists& l, const std::vector<uint8_t>* needed,
+                                     const uint8_t* d_in, int64_t in_frame_bytes,
                                      int in_stride, uint8_t* d_out, int64_t out_frame_bytes,
                                      int out_stride, int w, int h, int n_frames, int imagePlaneIndex,
                                      hipStream_t stream) {
-  if (!ensureTiles(p, w, h, imagePlaneIndex)) return false;
-  if (!p.full_cover) {
+  if (!ensureTiles(p, l, needed, w, h, imagePlaneIndex)) return false;
+  if (!l.full_cover) {
     // Mat::zeros(...) of filterPlane (:625): only visible where no segment writes
     for (int f = 0; f < n_frames; f++)
       if (!check(hipMemset2DAsync(d_out + (size_t)f * out_frame_bytes, (size_t)out_stride, 0, (size_t)w,
@@ -968,7 +988,7 @@ bool VideoFrameTransform::runLowpass(PlaneState& p, const uint8_t* d_in, int64_t
         return false;
   }
   LowpassArgs a;
-  fillLowpassArgs(p, d_in, in_frame_bytes, in_stride, d_out, out_frame_bytes, out_stride, w, h, &a);
+  fillLowpassArgs(p, l, d_in, in_frame_bytes, in_stride, d_out, out_frame_bytes, out_stride, w, h, &a);
   return check(launch_lowpass(a, n_frames, stream), "low-pass launch");
 }
 
@@ -1097,6 +1117,44 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     }
   }
 
+  // which of the two plans: every plane of the call must have the one that is used
+  // (nearest-neighbour plans hold 256-lane tiles only -- a pixel has no stencil halo to share with a wider tile -- so half
+  // the waves of an 8-wave workgroup would carry no pixels: 4-wave workgroups, four to a CU, at every batch length;
+  // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, tools/experiments_r04/call8.sh)
+  bool small = small_batch_ > 0 && (n_frames < small_batch_ || interp == NEAREST) && interp != LANCZOS4 && waves_ != 4;
+  {
+  // the planner's host copy of a map's sample LUT is fetched once per map even when both plans of the map end up being
+  // tried below, and is gone before anything is launched (up to 2^28 entries x 8 B per map)
+  std::vector<LutEntry> host_luts[kMaxMaps];
+  auto ensureGatherPlan = [&](PlaneState& ps, bool sm) { return this->ensureGatherPlan(ps, sm, &host_luts[&ps - planes_]); };
+  for (int k = 0; k < njobs; k++)
+    if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], small)) return false;
+  // (a map the 4-wave planner could not take but the 8-wave one can: every plane of the call then uses the latter)
+  for (int k = 0; k < njobs && small; k++) {
+    PlaneState& pk = planes_[jobs[k].idx];
+    if (!pk.plan_small.valid && pk.plan_ks != 0) {
+      if (!ensureGatherPlan(pk, false)) return false;
+      if (pk.plan.valid) small = false;
+    }
+  }
+  if (!small)
+    for (int k = 0; k < njobs; k++)
+      if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], false)) return false;
+  }
+  // Planes of a low-pass context whose long-batch plan fuses the filter into its tiles (nftiles > 0): the fused tiles read the
+  // RAW plane (remap_fused_kernel), the plan's other tiles the blurred one, and only the segments those still need are
+  // filtered.  The raw plane must be 16-byte friendly like any DMA source; if it is not, the plane takes the general
+  // gather over the fully filtered plane.
+  std::vector<char> lpf((size_t)njobs, 0), no_tiled((size_t)njobs, 0);
+  for (int k = 0; k < njobs && ctx_.enable_low_pass_filter && !barrel; k++) {
+    const PlaneJob& j = jobs[k];
+    const PlaneState& pk = planes_[j.idx];
+    const PlaneState::GatherPlan& gp = small ? pk.plan_small : pk.plan;
+    if (!gp.valid || gp.nftiles <= 0) continue;
+    const bool raw_ok = (reinterpret_cast<uintptr_t>(j.in) & 15) == 0 && (j.in_stride & 15) == 0 &&
+                        (n_frames <= 1 || (j.in_frame_bytes & 15) == 0) && (j.in_w & 15) == 0 && j.in_w == pk.in_w && j.in_h == pk.in_h;
+    (raw_ok ? lpf : no_tiled)[(size_t)k] = 1;
+  }
   // ---- stage 1: segmented low-pass into the scratch planes (filterPlane, :621-704) ----
   struct Src {
     const uint8_t* ptr;
@@ -1125,11 +1183,12 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
         PlaneState& pk = planes_[j.idx];
         for (int m = 0; m < k; m++) ok = ok && !(jobs[m].idx == j.idx && (jobs[m].in_w != j.in_w || jobs[m].in_h != j.in_h));
         if (!ok) break;
-        if (!ensureTiles(pk, j.in_w, j.in_h, j.image_plane)) return false;
+        PlaneState::LowpassLists& ll = lpf[(size_t)k] ? pk.lp_part : pk.lp;
+        if (!ensureTiles(pk, ll, lpf[(size_t)k] ? &pk.plan.seg_needed : nullptr, j.in_w, j.in_h, j.image_plane)) return false;
         const int bstride = (j.in_w + 255) & ~255;
-        fillLowpassArgs(pk, j.in, j.in_frame_bytes, j.in_stride, blurred_[scratch_].as<uint8_t>() + offs[(size_t)k],
+        fillLowpassArgs(pk, ll, j.in, j.in_frame_bytes, j.in_stride, blurred_[scratch_].as<uint8_t>() + offs[(size_t)k],
                         (int64_t)bstride * j.in_h, bstride, j.in_w, j.in_h, &la[k]);
-        ok = pk.full_cover;
+        ok = ll.full_cover;
       }
       if (ok && lowpass_mergeable(la, njobs)) {
         if (!check(launch_lowpass_multi(la, njobs, n_frames, stream_), "low-pass launch")) return false;
@@ -1152,8 +1211,9 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
         st = lp_streams_[k - 1];
         if (!check(hipStreamWaitEvent(st, lp_fork_, 0), "hipStreamWaitEvent")) return false;
       }
-      if (!runLowpass(planes_[j.idx], j.in, j.in_frame_bytes, j.in_stride, bl, plane_bytes, bstride, j.in_w, j.in_h,
-                      n_frames, j.image_plane, st))
+      PlaneState& pj = planes_[j.idx];
+      if (!runLowpass(pj, lpf[(size_t)k] ? pj.lp_part : pj.lp, lpf[(size_t)k] ? &pj.plan.seg_needed : nullptr, j.in, j.in_frame_bytes,
+                      j.in_stride, bl, plane_bytes, bstride, j.in_w, j.in_h, n_frames, j.image_plane, st))
         return false;
       if (side && k > 0 &&
           (!check(hipEventRecord(lp_join_[k - 1], st), "hipEventRecord") ||
@@ -1169,28 +1229,6 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // Planes with a tile plan and 16-byte friendly buffers go into fused launches of the LDS-tiled kernel
   // (up to 4 planes each: Y, U and V of a yuv420p batch are ONE launch); everything else -- BARREL outputs
   // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
-  // which of the two plans: every plane of the call must have the one that is used
-  // (nearest-neighbour plans hold 256-lane tiles only -- a pixel has no stencil halo to share with a wider tile -- so half
-  // the waves of an 8-wave workgroup would carry no pixels: 4-wave workgroups, four to a CU, at every batch length;
-  // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, tools/experiments_r04/call8.sh)
-  bool small = small_batch_ > 0 && (n_frames < small_batch_ || interp == NEAREST) && interp != LANCZOS4 && waves_ != 4;
-  // the planner's host copy of a map's sample LUT lives for this call only, and is fetched once per map even when both
-  // plans of the map end up being tried below
-  std::vector<LutEntry> host_luts[kMaxMaps];
-  auto ensureGatherPlan = [&](PlaneState& ps, bool sm) { return this->ensureGatherPlan(ps, sm, &host_luts[&ps - planes_]); };
-  for (int k = 0; k < njobs; k++)
-    if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], small)) return false;
-  // (a map the 4-wave planner could not take but the 8-wave one can: every plane of the call then uses the latter)
-  for (int k = 0; k < njobs && small; k++) {
-    PlaneState& pk = planes_[jobs[k].idx];
-    if (!pk.plan_small.valid && pk.plan_ks != 0) {
-      if (!ensureGatherPlan(pk, false)) return false;
-      if (pk.plan.valid) small = false;
-    }
-  }
-  if (!small)
-    for (int k = 0; k < njobs; k++)
-      if (!barrel && !ensureGatherPlan(planes_[jobs[k].idx], false)) return false;
   TiledArgs fused;
   auto reset_fused = [&]() {
     memset(&fused, 0, sizeof(fused));
@@ -1210,28 +1248,32 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     fused.k_hi = getenv("T360_K_HI") ? atoi(getenv("T360_K_HI")) : 0;
 #endif
   };
-  auto flush_fused = [&]() -> bool {
-    if (fused.nplanes == 0) return true;
+  // frames per work item, tail split and grid bookkeeping of a launch of the tiled (or the fused) kernel
+  auto finalize_launch = [&](TiledArgs& ta) {
     // A launch with fewer work items than 1.5 x the workgroups the GPU holds at once ends on a nearly empty machine
     // (BASELINE config 1: 576 tiles for 512 slots = one full round and one of 64 workgroups, 64 frames each): every
     // tile's frames are split into more runs until the items pass that mark (config 1, 64 frames: 0.082 -> 0.064 ms with
     // two runs of 32; 16 frames on the 4-wave plan: 0.023 -> 0.020 ms).  Runs stay >= 8 frames, a workgroup's start-up
     // being worth ~5 of them; BASELINE config 2 (1 152 tiles) is not affected.
     {
-      const int slots = cus_ * (fused.waves == 8 ? 2 : 4);
-      const int tiles = fused.total_tiles + fused.total_direct;
-      int runs = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+      const int slots = cus_ * (ta.waves == 8 ? 2 : 4);
+      const int tiles = ta.total_tiles + ta.total_direct;
+      int runs = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
       while (tiles > 0 && 2 * tiles * runs < 3 * slots && n_frames / (runs + 1) >= 8) runs++;
-      fused.frames_per_block = std::min(fused.frames_per_block, (n_frames + runs - 1) / runs);
+      ta.frames_per_block = std::min(ta.frames_per_block, (n_frames + runs - 1) / runs);
     }
-    fused.groups = (n_frames + fused.frames_per_block - 1) / fused.frames_per_block;
+    ta.groups = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
     // the tail tiles walk the batch in at least two runs of <= tail_frames_ frames, all of EQUAL length (20 frames:
     // 10 + 10, not 16 + 4: -6 %; 8 frames: 4 + 4: -2 %)
-    fused.tail_frames = std::max(1, std::min({fused.frames_per_block, tail_frames_, (n_frames + 1) / 2}));
-    fused.tail_groups = (n_frames + fused.tail_frames - 1) / fused.tail_frames;
-    fused.tail_frames = (n_frames + fused.tail_groups - 1) / fused.tail_groups;
-    fused.tail_percent = fused.tail_groups > fused.groups ? tail_percent_ : 0;
-    fused.direct_blocks = (fused.total_direct * fused.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
+    ta.tail_frames = std::max(1, std::min({ta.frames_per_block, tail_frames_, (n_frames + 1) / 2}));
+    ta.tail_groups = (n_frames + ta.tail_frames - 1) / ta.tail_frames;
+    ta.tail_frames = (n_frames + ta.tail_groups - 1) / ta.tail_groups;
+    ta.tail_percent = ta.tail_groups > ta.groups ? tail_percent_ : 0;
+    ta.direct_blocks = (ta.total_direct * ta.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
+  };
+  auto flush_fused = [&]() -> bool {
+    if (fused.nplanes == 0) return true;
+    finalize_launch(fused);
 #ifdef T360_INSTRUMENT
     t360::DeviceBuffer trace;
     const char* trace_path = getenv("T360_TRACE");
@@ -1271,6 +1313,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     return ok;
   };
   reset_fused();
+  // the fused low-pass tiles of the call's planes: one launch of remap_fused_kernel beside the tiled kernel's
+  FusedArgs lpa;
+  memset(&lpa, 0, sizeof(lpa));
+  lpa.base = fused;
   const bool multi = n_frames > 1;
   for (int k = 0; k < njobs; k++) {
     const PlaneJob& j = jobs[k];
@@ -1285,7 +1331,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     const bool vec_ok = (reinterpret_cast<uintptr_t>(s.ptr) & 15) == 0 && (s.stride & 15) == 0 &&
                         (!multi || (s.frame_bytes & 15) == 0) && (j.in_w & 15) == 0;
     const PlaneState::GatherPlan& gp = small ? p.plan_small : p.plan;
-    if (gp.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && vec_ok) {
+    if (gp.valid && !barrel && j.in_w == p.in_w && j.in_h == p.in_h && vec_ok && !no_tiled[(size_t)k]) {
       TiledPlane tp;
       memset(&tp, 0, sizeof(tp));
       tp.src = s.ptr;
@@ -1312,6 +1358,21 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       fused.plane[fused.nplanes++] = tp;
       fused.total_tiles += tp.ntiles;
       fused.total_direct += tp.ndirect;
+      if (lpf[(size_t)k] && lpa.base.nplanes < 4) {
+        TiledPlane fp = tp;
+        fp.src = j.in;  // the RAW plane: these tiles filter their own footprint
+        fp.src_frame_bytes = j.in_frame_bytes;
+        fp.sstride = j.in_stride;
+        fp.tiles = gp.ftiles.as<TileDesc>();
+        fp.tlut = gp.ftlut.as<uint32_t>();
+        fp.chunks = gp.fchunks.as<uint32_t>();
+        fp.ntiles = gp.nftiles;
+        fp.ndirect = fp.ndirect_top = 0;
+        fp.scatter = 0;
+        lpa.taps[lpa.base.nplanes] = p.fuse_taps.as<uint32_t>();
+        lpa.base.plane[lpa.base.nplanes++] = fp;
+        lpa.base.total_tiles += fp.ntiles;
+      }
       continue;
     }
     GatherArgs a;
@@ -1332,7 +1393,15 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     if (!check(launch_remap_gather(a, n_frames, stream_), "remap launch")) return false;
     setLastKernel("remap_gather_kernel");
   }
-  return flush_fused();
+  if (!flush_fused()) return false;
+  if (lpa.base.nplanes > 0) {
+    finalize_launch(lpa.base);
+    if (!check(launch_remap_fused(lpa, stream_), "fused remap launch")) return false;
+    char name[64];
+    snprintf(name, sizeof(name), "remap_fused_kernel<%d> + %s", lpa.base.ks, remap_tiled_kernel_name(lpa.base.ks, lpa.base.ring_kb, lpa.base.waves));
+    setLastKernel(name);
+  }
+  return true;
 }
 
 // Tile work list of the LDS-tiled gather for one map: the sample LUT is copied to the host and planned there
@@ -1393,6 +1462,10 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small, std::vecto
   o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
   o.row_pad = plan_row_pad_;
   o.row_align = plan_row_align_;
+  // long batches of a low-pass context: tiles whose source rows all have short fixed-point kernels filter their own
+  // footprint in LDS (remap_fused_kernel); the plan then also says which segments its other tiles still need blurred
+  if (!small && p.fuse_ok && ctx_.enable_low_pass_filter && waves == 8 && (ks == 2 || ks == 4) && o.scatter <= 0 && o.wide256_pct <= 0)
+    o.fuse = &p.fuse_info;
   HostGatherPlan hp;
   if (!plan_gather(host_lut.data(), p.map_w, p.map_h, p.in_w, p.in_h, o, &hp)) return true;
   if (!g.tiles.reserve(std::max<size_t>(hp.tiles.size(), 1) * sizeof(TileDesc)) ||
@@ -1407,6 +1480,23 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small, std::vecto
                             hipMemcpyHostToDevice, stream_), "hipMemcpy(chunks)") ||
       !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
     return false;
+  g.nftiles = 0;
+  g.seg_needed.clear();
+  if (hp.nftiles > 0) {
+    if (!g.ftiles.reserve(hp.ftiles.size() * sizeof(TileDesc)) || !g.ftlut.reserve(hp.ftlut.size() * sizeof(uint32_t)) ||
+        !g.fchunks.reserve(hp.fchunks.size() * sizeof(uint32_t)))
+      return check(hipErrorOutOfMemory, "hipMalloc(fused gather plan)");
+    if (!check(hipMemcpyAsync(g.ftiles.as<void>(), hp.ftiles.data(), hp.ftiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice,
+                              stream_), "hipMemcpy(ftiles)") ||
+        !check(hipMemcpyAsync(g.ftlut.as<void>(), hp.ftlut.data(), hp.ftlut.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              stream_), "hipMemcpy(ftlut)") ||
+        !check(hipMemcpyAsync(g.fchunks.as<void>(), hp.fchunks.data(), hp.fchunks.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              stream_), "hipMemcpy(fchunks)") ||
+        !check(hipStreamSynchronize(stream_), "hipStreamSynchronize"))
+      return false;
+    g.nftiles = hp.nftiles;
+    g.seg_needed = hp.seg_needed;
+  }
   g.ntiles = hp.ntiles;
   g.ndirect = hp.ndirect;
   g.ndirect_top = hp.ndirect_top;
@@ -1524,7 +1614,7 @@ bool VideoFrameTransform::filterPlane(const uint8_t* d_in, uint8_t* d_out, int w
     return false;
   }
   DeviceGuard g(device_);
-  return runLowpass(planes_[idx], d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx, stream_);
+  return runLowpass(planes_[idx], planes_[idx].lp, nullptr, d_in, 0, in_stride, d_out, 0, out_stride, width, height, 1, idx, stream_);
 }
 
 bool VideoFrameTransform::planStats(int idx, int64_t* st) const {

@@ -85,16 +85,25 @@ class VideoFrameTransform {
     } resize;
     // low-pass
     t360::FilterConfig filter;
-    t360::DeviceBuffer segs, taps_q8, taps_f32, taps_pk, tiles;
+    t360::DeviceBuffer segs, taps_q8, taps_f32, taps_pk, taps_sh;
     std::vector<int> seg_fast;       // per segment: eligible for the register-only Q8 kernel
     int fast_ky = 0;                 // vertical taps shared by the eligible segments (3, 5, 7; 0 = none)
-    int tiles_w = -1, tiles_h = -1;  // plane size the tile lists were built for
-    int ntiles = 0, max_rows = 0;    // generic tiles covering EVERY segment (any alignment)
-    // when the buffers are dword friendly: fast tiles of the eligible segments + generic tiles of the rest
-    t360::DeviceBuffer tiles_fast, tiles_rest, tiles_wide, taps_sh;
-    int nfast = 0, nrest = 0, max_rows_rest = 0, fast_lds_bytes = 0;
-    int nwide = 0, wide_lds_bytes = 0;  // seg_fast[i] == 2: the segment's runs go to the wide fast path
-    bool full_cover = false;
+    // the low-pass work lists of one plane size: every segment (`lp`), or -- when the long-batch gather plan fuses the
+    // low-pass into most of its tiles -- only the segments its UNFUSED tiles still read (`lp_part`)
+    struct LowpassLists {
+      int tiles_w = -1, tiles_h = -1;  // plane size the tile lists were built for
+      t360::DeviceBuffer tiles;
+      int ntiles = 0, max_rows = 0;    // generic tiles covering EVERY listed segment (any alignment)
+      // when the buffers are dword friendly: fast tiles of the eligible segments + generic tiles of the rest
+      t360::DeviceBuffer tiles_fast, tiles_rest, tiles_wide;
+      int nfast = 0, nrest = 0, max_rows_rest = 0, fast_lds_bytes = 0;
+      int nwide = 0, wide_lds_bytes = 0;  // seg_fast[i] == 2: the segment's runs go to the wide fast path
+      bool full_cover = false;
+    } lp, lp_part;
+    // fused low-pass tiles (t360_internal.h): what the planner needs, and the packed kernels on the device
+    t360::FuseInfo fuse_info;
+    t360::DeviceBuffer fuse_taps;
+    bool fuse_ok = false;
     // LDS-tiled gather: work list planned on the host at init (t360_plan.cpp)
     struct GatherPlan {
       bool valid = false, tried = false;             // tried: planning was attempted (valid or not plannable)
@@ -102,6 +111,11 @@ class VideoFrameTransform {
       int waves = 0, max_pieces = 0;                 // what it was planned for
       bool scatter = false;                          // chunk tables with block origins (scatter plan)
       t360::DeviceBuffer tiles, tlut, chunks;
+      // the fused low-pass work list of the plan (nftiles > 0: the tiles above read the BLURRED plane, these the raw one) and
+      // the segments the tiles above still need filtered
+      int nftiles = 0;
+      t360::DeviceBuffer ftiles, ftlut, fchunks;
+      std::vector<uint8_t> seg_needed;
       t360::PlanStats stats;
     } plan, plan_small;  // plan_small: workgroups of 4 waves, for batches shorter than small_batch_ frames
     int plan_ks = 0;                       // taps per axis the plans are for; 0: the tiled kernel cannot take this map
@@ -109,7 +123,7 @@ class VideoFrameTransform {
 
   bool check(hipError_t e, const char* what) const;
   bool ensureWeights();
-  bool ensureTiles(PlaneState& p, int w, int h, int imagePlaneIndex);
+  bool ensureTiles(PlaneState& p, PlaneState::LowpassLists& l, const std::vector<uint8_t>* needed, int w, int h, int imagePlaneIndex);
   bool buildGatherPlan(PlaneState& p, const t360::MapGenParams& P, int in_w, int in_h);
   bool ensureGatherPlan(PlaneState& p, bool small, std::vector<t360::LutEntry>* lut_of_this_call);
   // all-device core: a set of planes of n frames
@@ -126,9 +140,9 @@ class VideoFrameTransform {
   bool runPlanes(const PlaneJob* jobs, int njobs, int n_frames);
   bool runPlanesScaled(const PlaneJob* jobs, int njobs, int n_frames);
   bool buildResizePlan(PlaneState& p, int dw, int dh);
-  void fillLowpassArgs(const PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride, uint8_t* d_out,
+  void fillLowpassArgs(const PlaneState& p, const PlaneState::LowpassLists& l, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride, uint8_t* d_out,
                        int64_t out_frame_bytes, int out_stride, int w, int h, t360::LowpassArgs* out) const;
-  bool runLowpass(PlaneState& p, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
+  bool runLowpass(PlaneState& p, PlaneState::LowpassLists& l, const std::vector<uint8_t>* needed, const uint8_t* d_in, int64_t in_frame_bytes, int in_stride,
                   uint8_t* d_out, int64_t out_frame_bytes, int out_stride, int w, int h, int n_frames,
                   int imagePlaneIndex, hipStream_t stream);
 
@@ -168,6 +182,7 @@ class VideoFrameTransform {
   bool use_fast_lowpass_ = true;
   bool merge_lowpass_ = true;     // Y, U and V of a batch in one launch where the wide tiles serve all of them (T360_NO_MERGED_LOWPASS)
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
+  bool fuse_lowpass_ = true;      // long batches: tiles that can filter their own footprint do (instrumented build: T360_NO_FUSED_LOWPASS)
   // scratch planes: [0] for the calls on the handle's stream, [1 + lane] for the pipelined calls of that lane (calls on
   // different lanes overlap on the device and must not share intermediates)
   static constexpr int kMaxLanes = 4;
