@@ -371,6 +371,8 @@ class HipPath:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         self.t = handler.VideoFrameTransform(ctx)
+        if os.environ.get("T360_BENCH_FUSED_LOWPASS"):   # --fused-lowpass: A/B of T360_setFusedLowpass (off by default)
+            assert self.t.setFusedLowpass(True)
         for idx, k in ((0, 0), (1, 1)):
             assert self.t.generateMapForPlane(*lin.dims[k], *lout.dims[k], idx)
         assert self.t.setStream(self.stream)
@@ -1099,9 +1101,13 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2, help="internal streams of the pipelined legs (1..4)")
     ap.add_argument("--no-native", action="store_true", help="skip the leg that runs the native C++ driver (examples/t360_multi_gpu)")
     ap.add_argument("--two-handles", action="store_true", help="also time steps alternating between two handles on two streams (development)")
+    ap.add_argument("--fused-lowpass", action="store_true",
+                    help="config 3: T360_setFusedLowpass(1) -- the low-pass inside the gather tiles (off by default: slower, DESIGN.md 5.2)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the rank function with a stand-in transform (tests; never a benchmark result)")
     args = ap.parse_args()
+    if args.fused_lowpass:
+        os.environ["T360_BENCH_FUSED_LOWPASS"] = "1"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)

@@ -88,6 +88,14 @@ int T360_transformFramesPipelinedMany(VideoFrameTransform* transform, int n_call
 int T360_setPipelineDepth(VideoFrameTransform* transform, int depth);
 int T360_pipelineJoin(VideoFrameTransform* transform);
 
+/* Low-pass contexts, batches of >= 24 frames, bilinear / bicubic, MONO input: on = 1 makes the gather tiles whose source rows
+ * all have fixed-point kernels of <= 7 horizontal and 3 vertical taps filter their own footprint in LDS (ONE pass over the raw
+ * plane: reference filterPlane feeding remap, VideoFrameTransform.cpp:727-733 + :748-754, without the blurred plane's round
+ * trip through HBM); the other tiles and the segments they read keep the two-pass path.  Same bytes either way (bit-exact).
+ * OFF by default: on MI355X the filter is bound by integer VALU issue, not by HBM, and the fused kernel issues more of it
+ * (BASELINE config 3 0.68 ms fused against 0.55 ms two-pass).  Call before VideoFrameTransform_generateMapForPlane. */
+int T360_setFusedLowpass(VideoFrameTransform* transform, int on);
+
 /* Low-pass stage only (reference filterPlane, VideoFrameTransform.cpp:621-704) on one
  * device-resident plane; asynchronous.  For parity tests of the segmented filter. */
 int T360_filterPlane(VideoFrameTransform* transform, const uint8_t* d_in, uint8_t* d_out,

@@ -217,7 +217,7 @@ def test_filter_call_sequence_yuv420p(T, oracle_mod):
 
 
 # ---------------------------------------------------------------- batch entry point
-def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=4, pipelined=False):
+def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=4, pipelined=False, fused=False):
     """n frames x 3 planes through T360_transformFrames == per-plane oracle calls.  pipelined: the same batch three more
     times through T360_transformFramesPipelined (three lanes, three buffers) == the plain call's output, bit for bit."""
     import torch
@@ -232,12 +232,16 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=
     torch.cuda.synchronize()
     o = O.Oracle(ctx, threads=threads)
     with T.VideoFrameTransform(ctx) as t:
+        if fused:
+            assert t.setFusedLowpass(True)   # before the maps: tiles that can filter their own footprint in LDS do
         for idx, k in ((0, 0), (1, 1)):
             d = (*lin.dims[k], *lout.dims[k])
             assert t.generateMapForPlane(*d, idx) and o.generateMapForPlane(*d, idx)
         assert t.setStream(torch.cuda.current_stream())
         assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
         assert t.synchronize()
+        if fused:
+            assert "remap_fused_kernel" in t.lastKernel(), t.lastKernel()   # the path under test ran
         if pipelined:
             assert t.setPipelineDepth(3)
             outs = [torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda") for _ in range(3)]
@@ -599,6 +603,27 @@ def test_config3_batch_full_size_all_planes(T, oracle_mod):
     _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32,
                                     adjust_kernel=1, enable_multi_threading=1), n=25,
                 dims=(3840, 1920, 1536, 1024), extra_pad=0, threads=_threads())
+
+
+# T360_setFusedLowpass (round 6): the low-pass of a tile's own footprint done in LDS by the gather workgroup
+# (remap_fused_kernel; reference filterPlane feeding remap on one plane, VideoFrameTransform.cpp:727-733 + :748-754,
+# :173-204) -- same bytes as the two-pass path and the oracle, on BASELINE config 3 at full size, on the filter's default
+# 5 x 1 segments, on a small padded batch whose chroma tiles straddle three kernel bands, and with bilinear taps.
+@pytest.mark.parametrize("ov,n,dims,pad", [
+    (dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1), 25, (3840, 1920, 1536, 1024), 0),
+    (dict(interpolation_alg=CUBIC), 24, (3840, 1920, 1536, 1024), 0),                      # vf_transform360.c defaults: 5 x 1 segments
+    (dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1), 26, (960, 480, 384, 256), 64),
+    (dict(interpolation_alg=LINEAR, num_vertical_segments=9, num_horizontal_segments=4), 24, (1920, 960, 768, 512), 0),
+    (dict(interpolation_alg=CUBIC, fixed_yaw=33.0, fixed_pitch=-21.0, num_vertical_segments=15, num_horizontal_segments=8), 24, (1280, 640, 768, 512), 0),
+])
+def test_fused_lowpass_batches_equal_the_oracle(ov, n, dims, pad, T, oracle_mod):
+    _batch_case(T, oracle_mod, dict(enable_multi_threading=1, **ov), n=n, dims=dims, extra_pad=pad, threads=_threads(), fused=True)
+
+
+def test_fused_lowpass_pipelined_calls(T, oracle_mod):
+    """the fused path through three pipeline lanes (per-lane scratch planes for the segments the unfused tiles still read)"""
+    _batch_case(T, oracle_mod, dict(interpolation_alg=CUBIC, num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1),
+                n=24, dims=(1920, 960, 768, 512), extra_pad=0, threads=_threads(), pipelined=True, fused=True)
 
 
 def test_config1_batch_full_size_all_planes(T, oracle_mod):

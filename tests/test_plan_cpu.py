@@ -88,3 +88,49 @@ def test_packed_weights_reproduce_the_q15_table(interp, ks, sim, oracle_mod):
     unused = (256 * hi + lo).reshape(1024, ks, win * 4)[:, :, ks:]
     assert not unused.any()                                        # bilinear: bytes 2-3 of its window
     assert stride == 2 * nw                                        # nothing but the two halves (the kernel derives the bias)
+
+
+FUSED_CASES = {
+    "config3_luma": (dict(num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1), CUBIC, (3840, 1920, 1536, 1024)),
+    "config3_chroma": (dict(num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1), CUBIC, (1920, 960, 768, 512)),
+    "filter_defaults_5x1": (dict(), CUBIC, (1280, 640, 768, 512)),
+    "three_bands_per_tile": (dict(num_vertical_segments=15, num_horizontal_segments=32, adjust_kernel=1), CUBIC, (480, 240, 192, 128)),
+    "bilinear_9x4": (dict(num_vertical_segments=9, num_horizontal_segments=4), LINEAR, (960, 480, 384, 256)),
+    "rotated_ragged": (dict(num_vertical_segments=15, num_horizontal_segments=8, fixed_yaw=33.0, fixed_pitch=-21.0), CUBIC, (640, 320, 300, 200)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FUSED_CASES))
+def test_fused_lowpass_tiles_filter_and_gather_the_right_bytes(name, sim, oracle_mod):
+    """The fused low-pass work list of a plan (t360_internal.h "fused low-pass tiles"), emulated on the CPU: every fused tile's
+    RAW footprint is staged through its R chunk table, every lane's run is filtered with the kernel's integer arithmetic and
+    written in place, and the bytes under every pixel's stencil are compared with the oracle's filtered plane; the plan's
+    UNFUSED tiles are staged from a filtered plane in which every segment the plan does not list as needed is inverted; every
+    output pixel is covered exactly once."""
+    O = oracle_mod
+    ov, interp, (in_w, in_h, out_w, out_h) = FUSED_CASES[name]
+    ctx = filter_defaults(interpolation_alg=interp, enable_low_pass_filter=1, **ov)
+    o = O.Oracle(ctx, threads=4)
+    assert o.generateMapForPlane(in_w, in_h, out_w, out_h, 0)
+    q, _ = O.quantize_map(o.map(0))
+    lut = np.zeros(q.shape[:2] + (4,), np.int16)
+    lut[..., 0], lut[..., 1] = np.clip(q[..., 0], -32768, 32767), np.clip(q[..., 1], -32768, 32767)
+    lut[..., 2] = q[..., 2].astype(np.int16)
+    lut = np.ascontiguousarray(lut)
+    src = np.random.default_rng(5).integers(0, 256, (in_h, in_w), dtype=np.uint8)
+    blurred = o.filterPlane(src, 0)
+    row_kid, rects, taps, nsegs = np.zeros(in_h, np.int16), np.zeros(4 * 4096, np.int32), np.zeros(16 * 512, np.uint32), C.c_int()
+    sim.t360_host_fuse_info.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    nk = sim.t360_host_fuse_info(C.byref(ctx), in_w, in_h, out_w, out_h, row_kid.ctypes.data, rects.ctypes.data, 4096,
+                                 taps.ctypes.data, 512, C.byref(nsegs))
+    assert nk > 0 and (row_kid >= 0).any()
+    sim.t360_plan_verify_fused.restype = C.c_longlong
+    sim.t360_plan_verify_fused.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                                         C.c_void_p, C.c_void_p]
+    st = (C.c_longlong * 8)()
+    ks = {LINEAR: 2, CUBIC: 4}[interp]
+    bad = sim.t360_plan_verify_fused(lut.ctypes.data, out_w, out_h, in_w, in_h, ks, 24, src.ctypes.data, blurred.ctypes.data,
+                                     rects.ctypes.data, nsegs.value, row_kid.ctypes.data, taps.ctypes.data, st)
+    assert bad == 0
+    assert st[0] > 0                       # something was fused ...
+    assert st[3] < nsegs.value or st[1] + st[2] == 0 or name == "three_bands_per_tile"   # ... and fewer segments are needed

@@ -25,7 +25,7 @@ ADDITIVE_SYMBOLS = (
     "T360_version", "T360_deviceCount", "T360_setStream", "T360_useOwnStream", "T360_synchronize", "T360_transformFrames",
     "T360_filterPlane", "T360_getMapSize", "T360_copyMap", "T360_getSegmentCount", "T360_getSegment",
     "T360_copySegmentKernels", "T360_fillNoise", "T360_lastKernel", "T360_getPlanStats", "T360_buildFlags",
-    "T360_transformFramesPipelined", "T360_transformFramesPipelinedMany", "T360_setPipelineDepth", "T360_pipelineJoin",
+    "T360_transformFramesPipelined", "T360_transformFramesPipelinedMany", "T360_setPipelineDepth", "T360_pipelineJoin", "T360_setFusedLowpass",
 )
 
 
@@ -89,6 +89,7 @@ def load():
     L.T360_transformFramesPipelinedMany.argtypes = [vp, i, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_void_p), C.c_int64, i,
                                                     C.POINTER(T360PlaneDesc), i]
     L.T360_setPipelineDepth.argtypes = [vp, i]
+    L.T360_setFusedLowpass.argtypes = [vp, i]
     L.T360_pipelineJoin.argtypes = [vp]
     L.T360_getMapSize.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
     L.T360_copyMap.argtypes = [vp, i, vp]

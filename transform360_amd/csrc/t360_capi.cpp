@@ -132,6 +132,11 @@ T360_EXPORT int T360_transformFramesPipelinedMany(VideoFrameTransform* t, int n_
   });
 }
 
+T360_EXPORT int T360_setFusedLowpass(VideoFrameTransform* t, int on) {
+  if (!t) return 0;
+  return guarded("T360_setFusedLowpass", [&] { return t->setFusedLowpass(on != 0); });
+}
+
 T360_EXPORT int T360_setPipelineDepth(VideoFrameTransform* t, int depth) {
   if (!t) return 0;
   return guarded("T360_setPipelineDepth", [&] { return t->setPipelineDepth(depth); });

@@ -70,7 +70,9 @@ struct TiledArgs {
   int debug;                // instrumented build only (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA,
                             // bit2 skip direct tiles, bit3 skip 16x16 tiles, bit4 skip 4-px tiles, bit5 no copy B,
                             // bit6 every frame reads frame 0's source (L2 hits), bit7 no frame barrier, bit8 no output stores;
-                            // (right pixels) bit9 s_setprio 3 around the DMA issue, bit10 around the deferred store and the DMA issue
+                            // (right pixels) bit9 s_setprio 3 around the DMA issue, bit10 around the deferred store and the DMA issue;
+                            // remap_fused_kernel (WRONG PIXELS): bit0 no gather, bit1 no steady-state DMA, bit11 no filter pass,
+                            // bit12 no blurred writes, bit13 no second barrier
   unsigned long long* trace;  // instrumented build only: 8 timestamps (100 MHz) per workgroup (T360_TRACE)
   unsigned long long* phases; // instrumented build only: 2 x 8 cycle sums per workgroup (T360_PHASES)
 #endif

@@ -441,16 +441,14 @@ class Planner {
   bool emit_fused(Foot& f, HostGatherPlan* out) const {
     const TileShape& s = f.shape;
     const std::vector<int16_t>& row_kid = opt_.fuse->row_kid;
-    static const bool dbg = getenv("T360_PLAN_DEBUG") != nullptr;
-    auto why = [&](const char* w) { if (dbg) printf("unfused %s kind %d at %d,%d rows %d..%d\n", w, s.kind, f.ox, f.oy, f.y0, f.y0 + f.rows); return false; };
-    if (s.npx != 4 || s.kind == kTileScatter || f.y0 < 0 || f.y0 + f.rows > sh_ || f.rows + 2 > kBoxMaxRows) return why("shape/rows");
+    if (s.npx != 4 || s.kind == kTileScatter || f.y0 < 0 || f.y0 + f.rows > sh_ || f.rows + 2 > kBoxMaxRows) return false;
     std::vector<int> kid((size_t)f.rows, -1);
     for (int r = 0; r < f.rows; r++) {
       if (f.first[(size_t)r] < 0) continue;
       // (the filter replicates the plane's left / right edge where the gather wraps: the runs of the plane's first and last
       // dword column say so in their run words, and the kernel replaces the neighbour dword it would read across the edge)
       kid[(size_t)r] = row_kid[(size_t)(f.y0 + r)];
-      if (kid[(size_t)r] < 0) return why("kid");
+      if (kid[(size_t)r] < 0) return false;
     }
     // R rows t = 0 .. rows + 1 <-> source row y0 - 1 + t; chunk columns relative to the R box origin (c0 - 1)
     const int rrows = f.rows + 2;
@@ -468,15 +466,32 @@ class Planner {
         rlast[(size_t)a] = std::max(rlast[(size_t)a], hi);
       }
     }
+    // R placement: the LDS chunk position of a row is congruent to its source chunk column modulo 8 (128 bytes = one sweep
+    // of the 32 banks a ds_read_b32 sees), so the bank of a staged byte depends on its source x alone: the lanes of a filter
+    // read are neighbouring dword columns (run order below) and never meet on a bank, whatever rows their runs are in.
+    // Rows are chained greedily by the smallest gap, as in place(); a gap is LDS and DMA lanes, never HBM traffic.
     std::vector<int> rpos((size_t)rrows, 0);
     int rat = 0;
-    for (int t = 0; t < rrows; t++)
-      if (alias[(size_t)t] == t && rfirst[(size_t)t] >= 0) {
+    {
+      std::vector<int> todo;
+      for (int t = 0; t < rrows; t++)
+        if (alias[(size_t)t] == t && rfirst[(size_t)t] >= 0) todo.push_back(t);
+      while (!todo.empty()) {
+        size_t pick = 0;
+        int best = 8;
+        for (size_t i = 0; i < todo.size() && best > 0; i++) {
+          const int g = wrap(f.c0 - 1 + rfirst[(size_t)todo[i]] - rat, 8);
+          if (g < best) best = g, pick = i;
+        }
+        const int t = todo[pick];
+        todo.erase(todo.begin() + (long)pick);
+        rat += best;
         rpos[(size_t)t] = rat;
         rat += rlast[(size_t)t] - rfirst[(size_t)t] + 1;
       }
+    }
     const int slot_pos = std::max(rat, f.npos);
-    if (rat <= 0 || slot_pos > max_pos_) return why("budget");
+    if (rat <= 0 || slot_pos > max_pos_) return false;
     // runs: per B chunk column the maximal vertical spans of rows that hold it, cut where the kernel changes
     struct Span { int c, r0, len, kid; };
     std::vector<Span> spans;
@@ -492,11 +507,10 @@ class Planner {
       }
     }
     std::stable_sort(spans.begin(), spans.end(), [](const Span& a, const Span& b) {
-      return a.kid != b.kid ? a.kid < b.kid : a.r0 != b.r0 ? a.r0 < b.r0 : a.c < b.c;
+      return a.kid != b.kid ? a.kid < b.kid : a.c != b.c ? a.c < b.c : a.r0 < b.r0;
     });
     int ni = 0;
-    static const int min_ni = getenv("T360_PLAN_MIN_NI") ? atoi(getenv("T360_PLAN_MIN_NI")) : 1;
-    for (int cand = min_ni; cand <= kFusedMaxRun && ni == 0; cand++) {
+    for (int cand = 1; cand <= kFusedMaxRun && ni == 0; cand++) {
       int lanes = 0, in_kid = 0, prev = -1;
       for (const Span& sp : spans) {
         if (sp.kid != prev) lanes += (in_kid + 63) / 64 * 64, in_kid = 0, prev = sp.kid;
@@ -505,12 +519,7 @@ class Planner {
       lanes += (in_kid + 63) / 64 * 64;
       if (lanes <= kFusedLanes) ni = cand;
     }
-    if (ni == 0) return why("lanes");
-    if (dbg) {
-      std::set<int> ks_;
-      for (const Span& sp : spans) ks_.insert(sp.kid);
-      printf("fused ni %d kind %d pieces %d at %d,%d kids %d rows %d rat %d npos %d\n", ni, s.kind, (std::max(rat, f.npos) + 63) / 64, f.ox, f.oy, (int)ks_.size(), f.rows, rat, f.npos);
-    }
+    if (ni == 0) return false;
 
     TileDesc t{};
     t.ox = (int16_t)f.ox;
@@ -527,17 +536,26 @@ class Planner {
     const size_t cstride = (size_t)fused_chunk_dwords(mp), base = out->fchunks.size();
     out->fchunks.resize(base + cstride, 0);
     uint32_t* ct = &out->fchunks[base];
-    // R chunk table: rows are packed back to back, so the only positions without a chunk of their own lie behind the last row
-    uint32_t last_entry = 0;
+    // R chunk table; the gaps between rows and the positions behind the last one repeat their predecessor's chunk
+    std::fill(ct, ct + (size_t)mp * kPieceChunks, 0xffffffffu);
     for (int tr = 0; tr < rrows; tr++)
       if (alias[(size_t)tr] == tr && rfirst[(size_t)tr] >= 0) {
         const int sy = f.y0 - 1 + tr;
         for (int c = rfirst[(size_t)tr]; c <= rlast[(size_t)tr]; c++) {
           const int cx = wrap((f.c0 - 1 + c) * kStageChunk, sw_) / kStageChunk;
-          last_entry = ct[rpos[(size_t)tr] + c - rfirst[(size_t)tr]] = chunk_entry((uint32_t)sy, (uint32_t)cx);
+          ct[rpos[(size_t)tr] + c - rfirst[(size_t)tr]] = chunk_entry((uint32_t)sy, (uint32_t)cx);
         }
       }
-    for (int i = rat; i < mp * kPieceChunks; i++) ct[i] = last_entry;
+    {
+      uint32_t prev = 0xffffffffu;
+      for (int i = 0; i < mp * kPieceChunks && prev == 0xffffffffu; i++) prev = ct[i];
+      for (int i = 0; i < mp * kPieceChunks; i++) {
+        if (ct[i] == 0xffffffffu)
+          ct[i] = prev;
+        else
+          prev = ct[i];
+      }
+    }
     uint32_t* btab = ct + (size_t)mp * kPieceChunks;
     for (int r = 0; r < f.rows; r++) {
       const uint32_t v = (uint32_t)(uint16_t)(int16_t)(f.first[(size_t)r] < 0 ? 0 : row_base(f, r));
@@ -553,23 +571,33 @@ class Planner {
     uint32_t* winfo = runs + kFusedLanes;
     std::fill(runs, runs + kFusedLanes, kRunDead);
     {
-      int lane = 0, prev = -1, items = 0;
+      // lane order: kernel, then the run's index inside its column span, then the dword column -- the 32 lanes of an LDS
+      // access are then neighbouring dword columns (distinct banks under the x-only placement above), in similar rows
+      struct Run { int kid, k, d, a, len; };
+      std::vector<Run> rl;
+      int items = 0;
       for (const Span& sp : spans) {
-        if (sp.kid != prev) {
-          lane = (lane + 63) / 64 * 64;
-          prev = sp.kid;
-        }
         const int n = (sp.len + ni - 1) / ni;
         for (int k = 0; k < n; k++) {
           const int a = sp.r0 + (int)((int64_t)sp.len * k / n), b = sp.r0 + (int)((int64_t)sp.len * (k + 1) / n);
-          for (int j = 0; j < 4; j++, lane++) {
-            const int xabs = wrap((f.c0 + sp.c) * kStageChunk + 4 * j, sw_);
-            runs[lane] = (uint32_t)(sp.c * 4 + j) | ((uint32_t)a << 9) | ((uint32_t)(b - a) << 16) |
-                         (xabs == 0 ? kRunLeftEdge : 0u) | (xabs == sw_ - 4 ? kRunRightEdge : 0u);
-            winfo[lane / 64] = (uint32_t)sp.kid;
-          }
+          for (int j = 0; j < 4; j++) rl.push_back({sp.kid, k, sp.c * 4 + j, a, b - a});
           items += 4 * (b - a);
         }
+      }
+      std::stable_sort(rl.begin(), rl.end(), [](const Run& x, const Run& y) {
+        return x.kid != y.kid ? x.kid < y.kid : x.k != y.k ? x.k < y.k : x.d < y.d;
+      });
+      int lane = 0, prev = -1;
+      for (const Run& r : rl) {
+        if (r.kid != prev) {
+          lane = (lane + 63) / 64 * 64;
+          prev = r.kid;
+        }
+        const int xabs = wrap(f.c0 * kStageChunk + 4 * r.d, sw_);
+        runs[lane] = (uint32_t)r.d | ((uint32_t)r.a << 9) | ((uint32_t)r.len << 16) | (xabs == 0 ? kRunLeftEdge : 0u) |
+                     (xabs == sw_ - 4 ? kRunRightEdge : 0u);
+        winfo[lane / 64] = (uint32_t)r.kid;
+        lane++;
       }
       // lanes without a run of their own repeat the last run of their wave (a wave without any: the tile's last run and its
       // kernel): identical dwords written twice, and no lane of the filter phase is ever predicated off

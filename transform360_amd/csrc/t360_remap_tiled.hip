@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void fused_waves(const TiledArgs& a, const TiledPlane
   asm volatile("" : "+v"(half));
 
   // one frame's filter pass out of the slot at byte SLOT: blurred dwords of the run into bl[]
-  uint32_t bl[kFusedMaxRun];
+  uint32_t bl[kFusedMaxRun] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto filter = [&](auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;
     uint32_t res[3][4];
@@ -1104,16 +1104,16 @@ __device__ __forceinline__ void fused_waves(const TiledArgs& a, const TiledPlane
       const int fr = i + S;               /* frame filtered in this step; the gather handles frame fr - 1 */   \
       if (fr < nf) wait_vmcnt(min(K - 2, nf - 1 - fr) * per_frame);                                            \
       frame_barrier(); /* R(fr) is complete in slot S, B(fr - 1) in slot SP */                                 \
-      if (fr > 0 && has_px) pending = gather<NPX, KS, GROUP, SP * R::kSlot>(px, lds, dword_store);             \
+      if (fr > 0 && has_px && !T360_DBG(a, 0)) pending = gather<NPX, KS, GROUP, SP * R::kSlot>(px, lds, dword_store);             \
       asm volatile("" : "+v"(pending));                                                                        \
-      if (fr < nf) filter(std::integral_constant<int, S * R::kSlot>{});                                        \
-      frame_barrier(); /* every read of slot S (R) and of slot SP (B) is done */                               \
+      if (fr < nf && !T360_DBG(a, 11)) filter(std::integral_constant<int, S * R::kSlot>{});                    \
+      if (!T360_DBG(a, 13)) frame_barrier(); /* every read of slot S (R) and of slot SP (B) is done */         \
       if (fr > 0) {                                                                                            \
         if (has_px) emit<NPX, KS>(px, pending, d, doff, pl.dstride, dword_store, true);                        \
         d += pl.dst_frame_bytes;                                                                               \
       }                                                                                                        \
-      if (fr < nf) write_blurred(std::integral_constant<int, S * R::kSlot>{});                                 \
-      if (fr + K - 1 < nf) issue(f0 + fr + K - 1, SP * R::kSlot);                                              \
+      if (fr < nf && !T360_DBG(a, 12)) write_blurred(std::integral_constant<int, S * R::kSlot>{});             \
+      if (fr + K - 1 < nf && !T360_DBG(a, 1)) issue(f0 + fr + K - 1, SP * R::kSlot);                           \
     }
     T360_FSTEP(0) T360_FSTEP(1) T360_FSTEP(2)
 #undef T360_FSTEP

@@ -208,7 +208,8 @@ VideoFrameTransform::VideoFrameTransform(const FrameTransformContext* ctx) {
   if (getenv("T360_NO_FAST_LOWPASS")) use_fast_lowpass_ = false;
   if (getenv("T360_NO_WIDE_LOWPASS")) use_wide_lowpass_ = false;
   if (getenv("T360_NO_MERGED_LOWPASS")) merge_lowpass_ = false;
-  if (getenv("T360_NO_FUSED_LOWPASS")) fuse_lowpass_ = false;
+  if (getenv("T360_FUSED_LOWPASS")) fuse_lowpass_ = atoi(getenv("T360_FUSED_LOWPASS")) != 0;
+  if (getenv("T360_FUSED_SIDE_STREAM")) fuse_side_stream_ = atoi(getenv("T360_FUSED_SIDE_STREAM")) != 0;
 #endif
   ok_ = true;
 }
@@ -1155,6 +1156,98 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
                         (n_frames <= 1 || (j.in_frame_bytes & 15) == 0) && (j.in_w & 15) == 0 && j.in_w == pk.in_w && j.in_h == pk.in_h;
     (raw_ok ? lpf : no_tiled)[(size_t)k] = 1;
   }
+  TiledArgs fused;
+  auto reset_fused = [&]() {
+    memset(&fused, 0, sizeof(fused));
+    fused.wtab = weights_.as<int16_t>();
+    fused.wpack = weights_pack_.as<uint32_t>();
+    fused.nframes = n_frames;
+    fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
+    fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
+    // Lanczos4 plans hold 16x16 tiles only (one pixel per lane, 32 weight dwords each): workgroups of 4 waves
+    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
+    fused.ring_kb = (fused.ks == 8 && waves_ == 8) || small ? 38 : ring_kb_;
+    fused.waves = fused.ks == 8 || small ? 4 : waves_;
+#ifdef T360_INSTRUMENT
+    fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
+    fused.lds_pad = getenv("T360_LDS_PAD") ? atoi(getenv("T360_LDS_PAD")) : 0;
+    fused.k_lo = getenv("T360_K_LO") ? atoi(getenv("T360_K_LO")) : 0;
+    fused.k_hi = getenv("T360_K_HI") ? atoi(getenv("T360_K_HI")) : 0;
+#endif
+  };
+  // frames per work item, tail split and grid bookkeeping of a launch of the tiled (or the fused) kernel
+  auto finalize_launch = [&](TiledArgs& ta) {
+    // A launch with fewer work items than 1.5 x the workgroups the GPU holds at once ends on a nearly empty machine
+    // (BASELINE config 1: 576 tiles for 512 slots = one full round and one of 64 workgroups, 64 frames each): every
+    // tile's frames are split into more runs until the items pass that mark (config 1, 64 frames: 0.082 -> 0.064 ms with
+    // two runs of 32; 16 frames on the 4-wave plan: 0.023 -> 0.020 ms).  Runs stay >= 8 frames, a workgroup's start-up
+    // being worth ~5 of them; BASELINE config 2 (1 152 tiles) is not affected.
+    {
+      const int slots = cus_ * (ta.waves == 8 ? 2 : 4);
+      const int tiles = ta.total_tiles + ta.total_direct;
+      int runs = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
+      while (tiles > 0 && 2 * tiles * runs < 3 * slots && n_frames / (runs + 1) >= 8) runs++;
+      ta.frames_per_block = std::min(ta.frames_per_block, (n_frames + runs - 1) / runs);
+    }
+    ta.groups = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
+    // the tail tiles walk the batch in at least two runs of <= tail_frames_ frames, all of EQUAL length (20 frames:
+    // 10 + 10, not 16 + 4: -6 %; 8 frames: 4 + 4: -2 %)
+    ta.tail_frames = std::max(1, std::min({ta.frames_per_block, tail_frames_, (n_frames + 1) / 2}));
+    ta.tail_groups = (n_frames + ta.tail_frames - 1) / ta.tail_frames;
+    ta.tail_frames = (n_frames + ta.tail_groups - 1) / ta.tail_groups;
+    ta.tail_percent = ta.tail_groups > ta.groups ? tail_percent_ : 0;
+    ta.direct_blocks = (ta.total_direct * ta.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
+  };
+  reset_fused();
+  // The fused low-pass tiles of the call's planes: ONE launch of remap_fused_kernel.  It reads the raw planes only, so it does
+  // not wait for the low-pass launches below: it goes to a side stream first and runs beside them and beside the tiled
+  // kernel's launch for the plan's other tiles (joined at the end of the call).
+  bool lpa_launched = false;
+  char lpa_name[48] = "";
+  {
+    FusedArgs lpa;
+    memset(&lpa, 0, sizeof(lpa));
+    lpa.base = fused;
+    const bool multi = n_frames > 1;
+    for (int k = 0; k < njobs; k++) {
+      if (!lpf[(size_t)k] || lpa.base.nplanes >= 4) continue;
+      const PlaneJob& j = jobs[k];
+      PlaneState& p = planes_[j.idx];
+      const PlaneState::GatherPlan& gp = p.plan;
+      TiledPlane fp;
+      memset(&fp, 0, sizeof(fp));
+      fp.src = j.in;  // the RAW plane: these tiles filter their own footprint
+      fp.src_frame_bytes = j.in_frame_bytes;
+      fp.sstride = j.in_stride;
+      fp.dst = j.out;
+      fp.dst_frame_bytes = j.out_frame_bytes;
+      fp.sw = j.in_w;
+      fp.sh = j.in_h;
+      fp.dw = j.out_w;
+      fp.dh = j.out_h;
+      fp.dstride = j.out_stride;
+      fp.tiles = gp.ftiles.as<TileDesc>();
+      fp.tlut = gp.ftlut.as<uint32_t>();
+      fp.chunks = gp.fchunks.as<uint32_t>();
+      fp.lut = p.lut.as<LutEntry>();
+      fp.ntiles = gp.nftiles;
+      fp.dst_dword_ok = (reinterpret_cast<uintptr_t>(j.out) & 3) == 0 && (j.out_stride & 3) == 0 && (!multi || (j.out_frame_bytes & 3) == 0);
+      lpa.taps[lpa.base.nplanes] = p.fuse_taps.as<uint32_t>();
+      lpa.base.plane[lpa.base.nplanes++] = fp;
+      lpa.base.total_tiles += fp.ntiles;
+    }
+    if (lpa.base.nplanes > 0) {
+      finalize_launch(lpa.base);
+      hipStream_t fs = fuse_side_stream_ ? lp_streams_[2] : stream_;
+      if (fuse_side_stream_ &&
+          (!check(hipEventRecord(lp_fork_, stream_), "hipEventRecord") || !check(hipStreamWaitEvent(fs, lp_fork_, 0), "hipStreamWaitEvent")))
+        return false;
+      if (!check(launch_remap_fused(lpa, fs), "fused remap launch")) return false;
+      if (fuse_side_stream_ && !check(hipEventRecord(lp_join_[2], fs), "hipEventRecord")) return false;
+      lpa_launched = true;
+      snprintf(lpa_name, sizeof(lpa_name), "remap_fused_kernel<%d> + ", lpa.base.ks);
+    }
+  }
   // ---- stage 1: segmented low-pass into the scratch planes (filterPlane, :621-704) ----
   struct Src {
     const uint8_t* ptr;
@@ -1229,48 +1322,6 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // Planes with a tile plan and 16-byte friendly buffers go into fused launches of the LDS-tiled kernel
   // (up to 4 planes each: Y, U and V of a yuv420p batch are ONE launch); everything else -- BARREL outputs
   // (BORDER_TRANSPARENT), odd alignments or widths -- takes the general gather.
-  TiledArgs fused;
-  auto reset_fused = [&]() {
-    memset(&fused, 0, sizeof(fused));
-    fused.wtab = weights_.as<int16_t>();
-    fused.wpack = weights_pack_.as<uint32_t>();
-    fused.nframes = n_frames;
-    fused.frames_per_block = frames_per_block_ < n_frames ? frames_per_block_ : n_frames;
-    fused.ks = interp == NEAREST ? 1 : interp == LINEAR ? 2 : interp == CUBIC ? 4 : 8;
-    // Lanczos4 plans hold 16x16 tiles only (one pixel per lane, 32 weight dwords each): workgroups of 4 waves
-    fused.max_pieces = fused.ks == 8 ? std::min(max_pieces_, 16) : small ? kSmallPlanPieces : max_pieces_;
-    fused.ring_kb = (fused.ks == 8 && waves_ == 8) || small ? 38 : ring_kb_;
-    fused.waves = fused.ks == 8 || small ? 4 : waves_;
-#ifdef T360_INSTRUMENT
-    fused.debug = getenv("T360_DEBUG") ? atoi(getenv("T360_DEBUG")) : 0;
-    fused.lds_pad = getenv("T360_LDS_PAD") ? atoi(getenv("T360_LDS_PAD")) : 0;
-    fused.k_lo = getenv("T360_K_LO") ? atoi(getenv("T360_K_LO")) : 0;
-    fused.k_hi = getenv("T360_K_HI") ? atoi(getenv("T360_K_HI")) : 0;
-#endif
-  };
-  // frames per work item, tail split and grid bookkeeping of a launch of the tiled (or the fused) kernel
-  auto finalize_launch = [&](TiledArgs& ta) {
-    // A launch with fewer work items than 1.5 x the workgroups the GPU holds at once ends on a nearly empty machine
-    // (BASELINE config 1: 576 tiles for 512 slots = one full round and one of 64 workgroups, 64 frames each): every
-    // tile's frames are split into more runs until the items pass that mark (config 1, 64 frames: 0.082 -> 0.064 ms with
-    // two runs of 32; 16 frames on the 4-wave plan: 0.023 -> 0.020 ms).  Runs stay >= 8 frames, a workgroup's start-up
-    // being worth ~5 of them; BASELINE config 2 (1 152 tiles) is not affected.
-    {
-      const int slots = cus_ * (ta.waves == 8 ? 2 : 4);
-      const int tiles = ta.total_tiles + ta.total_direct;
-      int runs = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
-      while (tiles > 0 && 2 * tiles * runs < 3 * slots && n_frames / (runs + 1) >= 8) runs++;
-      ta.frames_per_block = std::min(ta.frames_per_block, (n_frames + runs - 1) / runs);
-    }
-    ta.groups = (n_frames + ta.frames_per_block - 1) / ta.frames_per_block;
-    // the tail tiles walk the batch in at least two runs of <= tail_frames_ frames, all of EQUAL length (20 frames:
-    // 10 + 10, not 16 + 4: -6 %; 8 frames: 4 + 4: -2 %)
-    ta.tail_frames = std::max(1, std::min({ta.frames_per_block, tail_frames_, (n_frames + 1) / 2}));
-    ta.tail_groups = (n_frames + ta.tail_frames - 1) / ta.tail_frames;
-    ta.tail_frames = (n_frames + ta.tail_groups - 1) / ta.tail_groups;
-    ta.tail_percent = ta.tail_groups > ta.groups ? tail_percent_ : 0;
-    ta.direct_blocks = (ta.total_direct * ta.groups + 7) & ~7;  // a multiple of 8: staged ids keep their XCD
-  };
   auto flush_fused = [&]() -> bool {
     if (fused.nplanes == 0) return true;
     finalize_launch(fused);
@@ -1313,10 +1364,6 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     return ok;
   };
   reset_fused();
-  // the fused low-pass tiles of the call's planes: one launch of remap_fused_kernel beside the tiled kernel's
-  FusedArgs lpa;
-  memset(&lpa, 0, sizeof(lpa));
-  lpa.base = fused;
   const bool multi = n_frames > 1;
   for (int k = 0; k < njobs; k++) {
     const PlaneJob& j = jobs[k];
@@ -1358,21 +1405,6 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       fused.plane[fused.nplanes++] = tp;
       fused.total_tiles += tp.ntiles;
       fused.total_direct += tp.ndirect;
-      if (lpf[(size_t)k] && lpa.base.nplanes < 4) {
-        TiledPlane fp = tp;
-        fp.src = j.in;  // the RAW plane: these tiles filter their own footprint
-        fp.src_frame_bytes = j.in_frame_bytes;
-        fp.sstride = j.in_stride;
-        fp.tiles = gp.ftiles.as<TileDesc>();
-        fp.tlut = gp.ftlut.as<uint32_t>();
-        fp.chunks = gp.fchunks.as<uint32_t>();
-        fp.ntiles = gp.nftiles;
-        fp.ndirect = fp.ndirect_top = 0;
-        fp.scatter = 0;
-        lpa.taps[lpa.base.nplanes] = p.fuse_taps.as<uint32_t>();
-        lpa.base.plane[lpa.base.nplanes++] = fp;
-        lpa.base.total_tiles += fp.ntiles;
-      }
       continue;
     }
     GatherArgs a;
@@ -1394,11 +1426,10 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
     setLastKernel("remap_gather_kernel");
   }
   if (!flush_fused()) return false;
-  if (lpa.base.nplanes > 0) {
-    finalize_launch(lpa.base);
-    if (!check(launch_remap_fused(lpa, stream_), "fused remap launch")) return false;
+  if (lpa_launched) {
+    if (fuse_side_stream_ && !check(hipStreamWaitEvent(stream_, lp_join_[2], 0), "hipStreamWaitEvent")) return false;
     char name[64];
-    snprintf(name, sizeof(name), "remap_fused_kernel<%d> + %s", lpa.base.ks, remap_tiled_kernel_name(lpa.base.ks, lpa.base.ring_kb, lpa.base.waves));
+    snprintf(name, sizeof(name), "%s%s", lpa_name, last_kernel_);
     setLastKernel(name);
   }
   return true;

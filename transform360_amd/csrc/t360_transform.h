@@ -57,6 +57,10 @@ class VideoFrameTransform {
   bool transformFramesPipelined(const uint8_t* d_in, int64_t in_frame_bytes, uint8_t* d_out,
                                 int64_t out_frame_bytes, int n_frames, const T360PlaneDesc* planes, int n_planes);
   bool setPipelineDepth(int depth);
+  bool setFusedLowpass(bool on) {  // takes effect for maps generated afterwards (t360_device.h)
+    fuse_lowpass_ = on;
+    return true;
+  }
   bool pipelineJoin();
   bool filterPlane(const uint8_t* d_in, uint8_t* d_out, int width, int height, int in_stride,
                    int out_stride, int map_index);
@@ -182,7 +186,9 @@ class VideoFrameTransform {
   bool use_fast_lowpass_ = true;
   bool merge_lowpass_ = true;     // Y, U and V of a batch in one launch where the wide tiles serve all of them (T360_NO_MERGED_LOWPASS)
   bool use_wide_lowpass_ = true;  // ... and its wide-tile variant (instrumented build: T360_NO_WIDE_LOWPASS)
-  bool fuse_lowpass_ = true;      // long batches: tiles that can filter their own footprint do (instrumented build: T360_NO_FUSED_LOWPASS)
+  bool fuse_side_stream_ = false; // the fused launch runs beside the low-pass and tiled launches of the call (instrumented build: T360_FUSED_SAME_STREAM)
+  bool fuse_lowpass_ = false;     // long batches: tiles that can filter their own footprint do (T360_setFusedLowpass; off by
+                                  // default: measured slower)
   // scratch planes: [0] for the calls on the handle's stream, [1 + lane] for the pipelined calls of that lane (calls on
   // different lanes overlap on the device and must not share intermediates)
   static constexpr int kMaxLanes = 4;

@@ -146,6 +146,10 @@ class VideoFrameTransform:
         return bool(self._l.T360_transformFramesPipelinedMany(self._h, n, ins, in_frame_bytes, outs, out_frame_bytes, n_frames,
                                                               descs, len(descs)))
 
+    def setFusedLowpass(self, on):
+        """before generateMapForPlane: long batches of a low-pass context filter inside the gather tiles (t360_device.h)"""
+        return bool(self._l.T360_setFusedLowpass(self._h, 1 if on else 0))
+
     def setPipelineDepth(self, depth):
         return bool(self._l.T360_setPipelineDepth(self._h, depth))
 
