@@ -1041,7 +1041,7 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
                            "why": "timed steps rotate through this much distinct input, several times the 256 MB Infinity Cache: a step "
                                   "whose input fits the cache would find it there, and even re-reading ONE 708 MB batch of config 2 every "
                                   "step measured 1 % faster than rotating through three (0.2370 vs 0.2395 ms, round 5, "
-                                  "tools/experiments_r05/call5.sh; rounds 1-4 did the former)"},
+                                  "profiles/r05_experiments/README.md call 5; rounds 1-4 did the former)"},
             "frames_timed_per_gpu": REPEATS * args.steps * h_F,
             # context for the timed region: `ms_per_step` x steps is a few milliseconds; over the
             # whole run this rank kept the GPU busy with transform steps (clock ramp, warm-up, every timed leg) for

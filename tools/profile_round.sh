@@ -26,7 +26,7 @@ trace_cfg() {
   grep -h "^{\"metric\"" "$OUT/trace$CFG.log" | tail -1 > "$R/profiles/${TAG}${SUF}_bench_under_rocprof.json"
 }
 # (config 2's trace runs at the END, next to the default line: the first processes on a freshly leased box run the same
-# launches 3-5 % slower than the ones a few minutes later -- tools/experiments_r05/call12.sh -- and the committed trace average
+# launches 3-5 % slower than the ones a few minutes later -- profiles/r05_experiments/README.md call 12 -- and the committed trace average
 # must be comparable with the committed line)
 for CFG in 1 3 4; do trace_cfg $CFG; done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace8" -o "$TAG" -- \

@@ -56,7 +56,7 @@ namespace {
 // that the slot base is an immediate of the consumer's ds_read (the frame loop is unrolled over the K slots):
 // most tiles stage 4-8 KiB and keep 4 frames in the ring, the few large ones near the poles 2-3.
 // frames in the ring of a workgroup, at most (per ring size, for A/B builds).  3 = two frames' DMA in flight.  Round 5
-// (tools/experiments_r05/call17.sh, call18.sh): with 4 the DMA-only time of a 64-frame launch does not move (0.2237 -> 0.2239 ms:
+// (profiles/r05_experiments/README.md calls 17, 18): with 4 the DMA-only time of a 64-frame launch does not move (0.2237 -> 0.2239 ms:
 // the memory side is not bound by the bytes a workgroup has in flight) and the whole launch is 1.5 % FASTER in the instrumented
 // build but 1.5 % SLOWER in the shipped configuration (0.2386 -> 0.2421, three interleaved rounds at +-0.1 %: the frame loop is
 // unrolled over the slots); 8-frame steps lose with 4 in both.
@@ -83,7 +83,7 @@ constexpr bool dual_copy(int ks) { return T360_DUAL != 0 && ks != 1; }
 #define T360_B64M 0
 #endif
 // T360_DMA_FIRST: 1 = the first frames' DMA is issued before the weight gather of the prologue (round 4: 0.2498 ->
-// 0.2427 ms per 64-frame launch on the same box; tools/experiments_r04/call1.sh)
+// 0.2427 ms per 64-frame launch on the same box; profiles/r04_experiments/README.md call 1)
 #ifndef T360_DMA_FIRST
 #define T360_DMA_FIRST 1
 #endif

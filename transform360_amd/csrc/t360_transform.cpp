@@ -1121,7 +1121,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
   // which of the two plans: every plane of the call must have the one that is used
   // (nearest-neighbour plans hold 256-lane tiles only -- a pixel has no stencil halo to share with a wider tile -- so half
   // the waves of an 8-wave workgroup would carry no pixels: 4-wave workgroups, four to a CU, at every batch length;
-  // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, tools/experiments_r04/call8.sh)
+  // config 1, 64 frames: 0.0652 -> 0.0621 ms on the same box, profiles/r04_experiments/README.md call 8)
   bool small = small_batch_ > 0 && (n_frames < small_batch_ || interp == NEAREST) && interp != LANCZOS4 && waves_ != 4;
   {
   // the planner's host copy of a map's sample LUT is fetched once per map even when both plans of the map end up being
@@ -1487,7 +1487,7 @@ bool VideoFrameTransform::ensureGatherPlan(PlaneState& p, bool small, std::vecto
   // nearest-neighbour maps: a pixel has no stencil halo, so by staged chunks a 32x32 tile always looked as good as a 64x16
   // one -- but its 77-byte row fragments touch 1.6 lines for every 0.6 they need.  Compared by the 128-byte lines under
   // their fragments the planner takes 64x16 tiles: BASELINE config 1, 64 frames 0.0639 -> 0.0579 ms on the same box
-  // (tools/experiments_r05/call8.sh)
+  // (profiles/r05_experiments/README.md call 8)
   o.cost_lines = plan_cost_lines_ != 0 || ks == 1;
   o.band = plan_band_ > 0 ? plan_band_ : 4;
   o.order = plan_band_ > 0 ? 0 : plan_band_ == 0 ? 1 : 2;
