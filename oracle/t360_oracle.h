@@ -102,6 +102,8 @@ int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep,
                         int left, int top, int width, int height,
                         const float* kx, int kx_len, const float* ky, int ky_len);
 int t360o_kernel_type(const float* k, int len); /* cv::getKernelType with the default anchor */
+/* tie-rounding variant of the two places where a SIMD build of OpenCV and its scalar code differ (t360_oracle_cv.c) */
+void t360o_set_cv_variant(int column_simd_lanes, int area_tail_lanes);
 
 /* cv::resize(..., INTER_AREA) for CV_8UC1, shrinking only (VideoFrameTransform.cpp:770-776);
  * returns 0 for requests it does not restate (enlargement). */

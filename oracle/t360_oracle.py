@@ -78,8 +78,17 @@ def lib():
         L.t360o_sepfilter_roi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                           C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.t360o_resize_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.t360o_set_cv_variant.argtypes = [C.c_int, C.c_int]
+        L.t360o_set_cv_variant.restype = None
         _lib = L
     return _lib
+
+
+def set_cv_variant(column_simd_lanes=0, area_tail_lanes=0):
+    """Which tie-rounding the restatement follows where a SIMD build of OpenCV 4.x and its scalar code differ
+    (t360_oracle_cv.c t360o_set_cv_variant); (0, 0) is the default the library is compared with."""
+    lib().t360o_set_cv_variant(column_simd_lanes, area_tail_lanes)
 
 
 def fnv1a64(arr):

@@ -11,7 +11,10 @@
  * createSeparableLinearFilter, FilterEngine ROI rules) following SURVEY.md Appendix A.
  * Known residual uncertainty (each <= 1 LSB, on exact ties only): OpenCV's SIMD column pass
  * of the fixed-point separable filter rounds half-to-even where this integer form rounds
- * half-up; the float filter path's tap pairing order.
+ * half-up; the float filter path's tap pairing order; the scalar tail of the 2 x 2 INTER_AREA
+ * fast path.  t360o_set_cv_variant() switches the first and the last to what a SIMD build of
+ * OpenCV 4.x computes (SymmColumnVec_32s8u; ResizeAreaFastVec's scalar remainder), so that the
+ * uncertainty can be COUNTED on real frames (tests/test_oracle_variants.py).
  */
 #include <float.h>
 #include <math.h>
@@ -273,6 +276,22 @@ int t360o_kernel_type(const float* k, int len) {
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* Which of two published evaluation orders the restatement follows where a SIMD build of OpenCV 4.x and its scalar
+ * code differ on exact ties (process-wide; test infrastructure).
+ *   column_simd_lanes > 0: the fixed-point column pass of cv::sepFilter2D as SymmColumnVec_32s8u does it for the first
+ *     width - width % lanes pixels of every filtered ROI row (filter.simd.hpp: the int32 row sums converted to float, the
+ *     Q8 taps as float(k / 65536), v_muladd, v_round = round half to EVEN, saturating pack) and as FixedPtCastEx does it
+ *     for the remaining pixels ((s + 32768) >> 16: round half UP).  v_uint8::nlanes = 16 for the 128-bit baseline
+ *     (SSE2 / NEON), 32 for an AVX2 baseline.  0 (default): the integer form everywhere.
+ *   area_tail_lanes > 0: the 2 x 2 INTER_AREA fast path as ResizeAreaFastVec_SIMD_8u + its scalar remainder: the first
+ *     dw - dw % lanes pixels of a row (sum + 2) >> 2, the rest saturate_cast<uchar>(sum * 0.25f) = round half to even
+ *     (resize.cpp; v_uint16::nlanes = 8 for the 128-bit baseline).  0 (default): (sum + 2) >> 2 everywhere. */
+static int g_column_simd_lanes = 0, g_area_tail_lanes = 0;
+void t360o_set_cv_variant(int column_simd_lanes, int area_tail_lanes) {
+  g_column_simd_lanes = column_simd_lanes;
+  g_area_tail_lanes = area_tail_lanes;
+}
+
 /* ---- cv::sepFilter2D on an ROI of a parent image (no BORDER_ISOLATED) ---- */
 int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep, uint8_t* dparent,
                         size_t dstep, int left, int top, int width, int height, const float* kx,
@@ -303,9 +322,19 @@ int t360o_sepfilter_roi(const uint8_t* parent, int pw, int ph, size_t pstep, uin
         R[x] = s;
       }
     }
+    /* SymmColumnVec_32s8u: symmetric kernels only (the fixed-point path implies it), ksize >= 3 */
+    const int simd_w = (g_column_simd_lanes > 0 && ky_len >= 3) ? width - width % g_column_simd_lanes : 0;
     for (int y = 0; y < height; y++) {
       uint8_t* D = dparent + (size_t)(top + y) * dstep + left;
-      for (int x = 0; x < width; x++) {
+      for (int x = 0; x < simd_w; x++) {
+        /* kernel.convertTo(CV_32F, 1. / (1 << 16)); s = S[0] * ky[0] + delta; s += (S[k] + S[-k]) * ky[k], k = 1..ry */
+        float sf = (float)rows[(size_t)(y + ry) * width + x] * (float)((double)kyi[ry] * (1.0 / 65536.0)) + 0.f;
+        for (int k = 1; k <= ry; k++)
+          sf = (float)(rows[(size_t)(y + ry + k) * width + x] + rows[(size_t)(y + ry - k) * width + x]) *
+                   (float)((double)kyi[ry + k] * (1.0 / 65536.0)) + sf;
+        D[x] = sat_u8(cv_round_f(sf));
+      }
+      for (int x = simd_w; x < width; x++) {
         int s = 0;
         for (int k = 0; k < ky_len; k++) s += kyi[k] * rows[(size_t)(y + k) * width + x];
         /* FixedPtCastEx<int, uchar>(16) */
@@ -480,7 +509,7 @@ int t360o_resize_area(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t*
           const uint8_t* S = src + (size_t)(dy * iscale_y + sy) * sstep + (size_t)dx * iscale_x;
           for (int sx = 0; sx < iscale_x; sx++) sum += S[sx];
         }
-        if (iscale_x == 2 && iscale_y == 2) {
+        if (iscale_x == 2 && iscale_y == 2 && !(g_area_tail_lanes > 0 && dx >= dw - dw % g_area_tail_lanes)) {
           D[dx] = (uint8_t)((sum + 2) >> 2);
         } else {
           long v = lrintf((float)sum * scale);
