@@ -2,7 +2,9 @@
 // for the host, so that tile shapes, fetched bytes and modelled LDS bank conflicts can be compared offline
 // (tests/plan_sim/plan_sim.py feeds it the oracle's LUT).  Development tool, not part of the library.
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "t360_filtercfg.h"
 #include "t360_plan.h"
@@ -393,4 +395,56 @@ extern "C" int t360_host_fuse_info(const FrameTransformContext* ctx, int inW, in
   for (int y = 0; y < inH; y++) row_kid[y] = fi.row_kid[(size_t)y];
   memcpy(taps, packed.data(), packed.size() * sizeof(uint32_t));
   return any ? (int)(packed.size() / t360::kFusedTapDwords) : 0;
+}
+
+// ---- request model (round 6) -----------------------------------------------------------------
+// TCP -> TCC read requests of the staging per frame: every DMA instruction (one 1 KiB piece: 64 lanes x 16 bytes) asks its
+// CU's L1 for the distinct 128-byte lines under its 64 chunks -- the L1 does not keep lines between the instructions of a
+// streaming kernel, so that is the number of requests it sends on to the L2 -- next to the tile-level line count (distinct
+// lines per TILE: what the L2 is asked for if a workgroup's own pieces never repeat a line) and the staged bytes.
+// out[kind * 4 + 0..3] = tiles, pieces, requests (distinct lines per instruction, summed), distinct lines per tile (summed);
+// kind 0..7 as kTile*, row 8 = all staged tiles.  Returns the tile count.
+extern "C" int t360_plan_requests(const t360::LutEntry* lut, int dw, int dh, int sw, int sh, int ks, int max_pieces, int waves,
+                                  int cost_lines, long long* out /*[9 * 4]*/) {
+  using namespace t360;
+  PlanOptions o;
+  o.ks = ks;
+  o.max_pieces = max_pieces;
+  o.waves = waves & 0xff;
+  o.wide256_pct = (waves >> 8) & 0xfff;   // the packing of t360_plan_verify
+  o.scatter = (waves >> 24) & 0xf;
+  o.cost_lines = cost_lines != 0 || ((waves >> 20) & 1) != 0;
+  HostGatherPlan plan;
+  if (!plan_gather(lut, dw, dh, sw, sh, o, &plan)) return -1;
+  const int mp = max_pieces < kMaxPieces ? max_pieces : kMaxPieces;
+  const size_t cstride = (size_t)tile_chunk_dwords(mp, plan.scatter);
+  for (int i = 0; i < 36; i++) out[i] = 0;
+  std::vector<uint32_t> seen;
+  for (int ti = 0; ti < plan.ntiles; ti++) {
+    const TileDesc& t = plan.tiles[(size_t)ti];
+    const uint32_t* tc = &plan.chunks[(size_t)ti * cstride];
+    long long req = 0;
+    std::vector<uint32_t> tile_lines;
+    for (int p = 0; p < t.pieces; p++) {
+      seen.clear();
+      for (int l = 0; l < kPieceChunks; l++) {
+        const uint32_t e = tc[p * kPieceChunks + l];
+        const uint32_t line = ((e >> 12) << 12) | ((e & 4095u) >> 3);
+        bool dup = false;
+        for (uint32_t s : seen) dup = dup || s == line;
+        if (!dup) seen.push_back(line);
+      }
+      req += (long long)seen.size();
+      tile_lines.insert(tile_lines.end(), seen.begin(), seen.end());
+    }
+    std::sort(tile_lines.begin(), tile_lines.end());
+    const long long distinct = (long long)(std::unique(tile_lines.begin(), tile_lines.end()) - tile_lines.begin());
+    for (int row : {(int)t.kind, 8}) {
+      out[row * 4 + 0] += 1;
+      out[row * 4 + 1] += t.pieces;
+      out[row * 4 + 2] += req;
+      out[row * 4 + 3] += distinct;
+    }
+  }
+  return plan.ntiles;
 }

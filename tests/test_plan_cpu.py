@@ -134,3 +134,19 @@ def test_fused_lowpass_tiles_filter_and_gather_the_right_bytes(name, sim, oracle
     assert bad == 0
     assert st[0] > 0                       # something was fused ...
     assert st[3] < nsegs.value or st[1] + st[2] == 0 or name == "three_bands_per_tile"   # ... and fewer segments are needed
+
+
+def test_request_model_matches_the_measured_l1_requests(oracle_mod):
+    """tests/plan_sim/request_model.py: the distinct 128-byte lines under every 1 KiB DMA instruction
+    of the shipped plan, summed over the planes of BASELINE config 2 and 64 frames, against TCP_TCC_READ_REQ of the profiled
+    launch (profiles/r05_pmc_summary.txt: 14.18 M; the remainder is the pole tiles' direct loads and the per-tile tables)."""
+    import plan_sim
+    import request_model
+    L = plan_sim.build()
+    req = pieces = 0
+    for plane, copies in ((0, 1), (1, 2)):
+        rows, _ = request_model.model(L, 2, plane, 24, 8)
+        req += copies * rows[8][2]
+        pieces += copies * rows[8][1]
+    assert 0.88 <= req * 64 / 14176454.1 <= 1.0
+    assert 13.0 <= req / pieces <= 14.5          # requests per staged KiB (whole-line staging would need 8)
