@@ -5,11 +5,14 @@
 // GPU under torch.distributed; this file is what an integrator who links -lTransform360 -lrccl would write.
 //
 //   make -C examples && examples/t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K]
-//                                                  [--pipelined D] [--gather]
+//                                                  [--pipelined D] [--gather | --gather-local]
 //
 // --workers W > devices rehearses the W-GPU process on fewer GPUs (workers share devices; no gather then);
 // --total-frames 64 is BASELINE configs[4] as written (64 frames sharded over the workers: strong scaling);
-// --pipelined D issues the steps through T360_transformFramesPipelined on D internal streams per handle.
+// --pipelined D issues the steps through T360_transformFramesPipelined on D internal streams per handle;
+// --gather-local runs the gather of --gather -- the same per-step operation lists (t360_shard_plan.h gather_ops), the same two
+// output buffers and events -- with device copies in place of ncclSend / ncclRecv, so that workers that SHARE a device (which
+// RCCL refuses to put into one communicator) move real bytes through it; both forms end with a check of the sink's checksum.
 //
 // Workload: BASELINE config 2 (3840x1920 yuv420p -> 1536x1024 CUBEMAP_32, bicubic, low-pass off), F frames per device
 // and step, resident in device memory.  Prints one line per device and the aggregate rate; the checksum of device d's
@@ -97,7 +100,7 @@ int main(int argc, char** argv) {
   using namespace t360_example;
   const int visible = T360_deviceCount();
   int ndev = visible, workers = 0, F = 64, steps = 20, total_frames = 0, depth = 0, ring_mb = 320;
-  bool gather = false;
+  bool gather = false, gather_local = false;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--devices") && i + 1 < argc) ndev = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--workers") && i + 1 < argc) workers = atoi(argv[++i]);
@@ -107,6 +110,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--pipelined") && i + 1 < argc) depth = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--ring-mb") && i + 1 < argc) ring_mb = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--gather")) gather = true;
+    else if (!strcmp(argv[i], "--gather-local")) gather = gather_local = true;
     else {
       fprintf(stderr, "usage: t360_multi_gpu [--devices N] [--workers W] [--frames F | --total-frames T] [--steps K] [--pipelined D] [--ring-mb M] [--gather]\n");
       return 2;
@@ -122,7 +126,7 @@ int main(int argc, char** argv) {
   if (workers <= 0) workers = ndev;
   std::vector<int> device_of((size_t)workers);
   for (int w = 0; w < workers; w++) device_of[(size_t)w] = w % ndev;
-  if (gather && !gather_possible(device_of)) {
+  if (gather && !gather_local && !gather_possible(device_of)) {
     if (workers == 1) {
       // one worker has nobody to gather from: the communicator is still initialised and the (empty) groups are posted, so
       // that the RCCL side of the driver can be exercised on a one-GPU box
@@ -148,7 +152,20 @@ int main(int argc, char** argv) {
   for (int w = 0; w < workers; w++) sink_bytes += out_bytes_of[(size_t)w] = (int64_t)(hi[(size_t)w] - lo[(size_t)w]) * lout.frame_bytes;
 
   std::vector<ncclComm_t> comms((size_t)workers);
-  if (gather) CHECK_NCCL(ncclCommInitAll(comms.data(), workers, device_of.data()));
+  if (gather && !gather_local) CHECK_NCCL(ncclCommInitAll(comms.data(), workers, device_of.data()));
+  // --gather-local: what a send / recv pair becomes when both ends may sit on one device.  Worker r announces (host side) that
+  // the `done` event of its gathered step number q is recorded; worker 0 then makes its side stream wait for that event,
+  // copies the frames into the sink and records `copied`; worker r waits for that event before it writes the buffer again.
+  struct LocalLink {
+    std::mutex mu;
+    std::condition_variable cv;
+    long posted = 0, pulled = 0;  // gathered steps whose `done` event is recorded / whose copy is issued
+    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    uint8_t* buf[2] = {nullptr, nullptr};
+  };
+  std::vector<LocalLink> links((size_t)workers);
+  unsigned long long sink_sum = 0;
+  bool sink_checked = false;
   std::vector<double> ms((size_t)workers);
   std::vector<unsigned long long> sums((size_t)workers);
   // the workers enter their timed loops TOGETHER (their warm-ups end at different times, and a worker timed while the
@@ -204,6 +221,16 @@ int main(int argc, char** argv) {
       CHECK_HIP(hipEventCreateWithFlags(&sent[b], hipEventDisableTiming));
     }
     const std::vector<P2POp> ops = gather ? gather_ops(w, out_bytes_of) : std::vector<P2POp>();
+    if (gather_local) {
+      LocalLink& me = links[(size_t)w];
+      for (int b = 0; b < 2; b++) {
+        CHECK_HIP(hipEventCreateWithFlags(&me.done[b], hipEventDisableTiming));
+        CHECK_HIP(hipEventCreateWithFlags(&me.copied[b], hipEventDisableTiming));
+        me.buf[b] = d_out[(size_t)b];
+      }
+      gate();  // every worker's events and buffers exist before anyone's first gathered step
+    }
+    long seq = 0;  // gathered steps of this worker so far (warm-up included): the same number on every worker
     auto transform = [&](uint8_t* out) {
       if (nf == 0) return;
       const uint8_t* in = d_in + (size_t)in_group * step_in;
@@ -215,6 +242,43 @@ int main(int argc, char** argv) {
     auto step = [&](int k) {
       if (!gather) {
         transform(d_out[(size_t)(k % nbuf)]);
+        return;
+      }
+      if (gather_local) {
+        const long q = seq++;
+        const int b = buffer_of_step((int)(q & 1));
+        LocalLink& me = links[(size_t)w];
+        if (w != 0 && q >= 2) {
+          // the copy that read this buffer (gathered step q - 2) is issued: wait for it on the device
+          std::unique_lock<std::mutex> lk(me.mu);
+          me.cv.wait(lk, [&] { return me.pulled >= q - 1; });
+          lk.unlock();
+          CHECK_HIP(hipStreamWaitEvent(stream, me.copied[b], 0));
+        }
+        transform(d_out[(size_t)b]);
+        if (depth > 0 && !T360_pipelineJoin(t)) exit(1);
+        CHECK_HIP(hipEventRecord(me.done[b], stream));
+        {
+          std::lock_guard<std::mutex> lk(me.mu);
+          me.posted = q + 1;
+        }
+        me.cv.notify_all();
+        for (const P2POp& op : ops) {
+          if (op.send) continue;  // the sending side of a local pair is the announcement above
+          LocalLink& peer = links[(size_t)op.peer];
+          {
+            std::unique_lock<std::mutex> lk(peer.mu);
+            peer.cv.wait(lk, [&] { return peer.posted >= q + 1; });
+          }
+          CHECK_HIP(hipStreamWaitEvent(side, peer.done[b], 0));
+          CHECK_HIP(hipMemcpyAsync(sink + op.offset, peer.buf[b], (size_t)op.bytes, hipMemcpyDeviceToDevice, side));
+          CHECK_HIP(hipEventRecord(peer.copied[b], side));
+          {
+            std::lock_guard<std::mutex> lk(peer.mu);
+            peer.pulled = q + 1;
+          }
+          peer.cv.notify_all();
+        }
         return;
       }
       const int b = buffer_of_step(k);
@@ -253,14 +317,31 @@ int main(int argc, char** argv) {
     ms[(size_t)w] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     gate();
     if (w == 0) t_end = std::chrono::steady_clock::now();
-    // the checksum is of the stream's own frames (group 0): one more plain step, outside the timed region
+    // the checksum is of the stream's own frames (group 0): one more step, outside the timed region -- with a gather, a
+    // gathered step into buffer 0 (`steps` and the warm-up are even), so that the sink holds exactly these frames afterwards
     in_group = 0;
-    if (nf > 0 && (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[0], lout.frame_bytes, nf, planes, 3) || !T360_synchronize(t))) exit(1);
+    if (gather) {
+      if (steps & 1) step(steps);  // keep the buffer parity: the checked step must use buffer 0
+      step(steps + (steps & 1));
+      if (!T360_synchronize(t)) exit(1);
+      CHECK_HIP(hipStreamSynchronize(side));
+      gate();  // every worker's last step, and worker 0's copies / receives, are complete
+      CHECK_HIP(hipStreamSynchronize(side));
+    } else if (nf > 0 && (!T360_transformFrames(t, d_in, lin.frame_bytes, d_out[0], lout.frame_bytes, nf, planes, 3) || !T360_synchronize(t))) {
+      exit(1);
+    }
     std::vector<uint8_t> host((size_t)nf * lout.frame_bytes);
     if (nf > 0) CHECK_HIP(hipMemcpy(host.data(), d_out[0], host.size(), hipMemcpyDeviceToHost));
     unsigned long long s = 0;
     for (uint8_t v : host) s += v;
     sums[(size_t)w] = s;
+    if (gather && w == 0 && sink_bytes > out_bytes_of[0]) {
+      // the frames of workers 1.. as they arrived in the sink (worker 0's own stay in its output buffer)
+      std::vector<uint8_t> hs((size_t)(sink_bytes - out_bytes_of[0]));
+      CHECK_HIP(hipMemcpy(hs.data(), sink + out_bytes_of[0], hs.size(), hipMemcpyDeviceToHost));
+      for (uint8_t v : hs) sink_sum += v;
+      sink_checked = true;
+    }
     VideoFrameTransform_delete(t);
     CHECK_HIP(hipFree(d_in));
     for (int b = 0; b < nbuf; b++) CHECK_HIP(hipFree(d_out[(size_t)b]));
@@ -281,7 +362,14 @@ int main(int argc, char** argv) {
          total_frames > 0 ? "strong" : "weak", gather ? "outputs gathered on worker 0" : "compute only",
          depth > 0 ? ", pipelined calls" : "", (double)frames_per_step * steps / (worst * 1e-3) * 1.572864,
          (double)frames_per_step * steps / (worst * 1e-3), worst / steps, frames_per_step);
-  if (gather)
+  if (gather && !gather_local)
     for (ncclComm_t c : comms) ncclCommDestroy(c);
+  if (sink_checked) {
+    unsigned long long want = 0;
+    for (int w = 1; w < workers; w++) want += sums[(size_t)w];
+    printf("gather check (%s): the sink holds %llu, workers 1..%d computed %llu: %s\n", gather_local ? "device copies" : "RCCL send / recv",
+           sink_sum, workers - 1, want, sink_sum == want ? "ok" : "MISMATCH");
+    if (sink_sum != want) return 1;
+  }
   return 0;
 }

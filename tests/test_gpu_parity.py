@@ -910,3 +910,22 @@ def test_native_multi_gpu_driver_matches_the_python_path(T):
     out = subprocess.run([exe, "--workers", "2", "--total-frames", str(2 * F), "--steps", "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert int(out.stdout.split("output checksum")[1].split()[0]) == want
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipelined", "2"]])
+def test_native_driver_gathers_real_bytes_between_workers_on_one_device(extra):
+    """examples/t360_multi_gpu --gather-local: three workers share this box's GPU and the outputs of
+    workers 1 and 2 travel to worker 0's sink through the driver's own per-step operation lists, double buffering and
+    events -- device copies standing in for ncclSend / ncclRecv, which RCCL refuses between ranks on one device -- for
+    warm-up, timed and final steps; the sink must then hold exactly the bytes workers 1 and 2 computed."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "t360_multi_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("examples/t360_multi_gpu not built (make -C examples; __graft_entry__.build() does it)")
+    out = subprocess.run([exe, "--devices", "1", "--workers", "3", "--total-frames", "10", "--steps", "6", "--gather-local"] + extra,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gather check (device copies)" in out.stdout and out.stdout.rstrip().endswith(": ok"), out.stdout
+    sums = [int(line.split("output checksum")[1].split()[0]) for line in out.stdout.splitlines() if "output checksum" in line]
+    assert len(sums) == 3 and len(set(sums)) == 3      # three different shards of the stream
