@@ -72,6 +72,9 @@ int T360_transformFrames(VideoFrameTransform* transform,
  *     handle's stream AND all lanes are idle;
  *   - calls k and k + depth run on the same lane, in order: an output buffer may be reused every `depth` calls.
  * depth: 1..4, default 2 (set with T360_setPipelineDepth before the first pipelined call or after a join).
+ * Not for use while the handle's stream is being captured into a HIP graph: a pipelined call asks the stream whether it is
+ * idle (hipStreamQuery) and, when tables are rebuilt, waits for the device -- both end a capture.  T360_transformFrames has
+ * no such restriction.
  * Same arithmetic, same kernels, same return convention as T360_transformFrames. */
 int T360_transformFramesPipelined(VideoFrameTransform* transform,
                                   const uint8_t* d_in, int64_t in_frame_bytes,
@@ -122,6 +125,9 @@ int T360_copySegmentKernels(VideoFrameTransform* transform, int map_index, int i
  * frames and single-plane calls run "<4, 38, 4>") or "remap_gather_kernel"; "" before the first call.  The pointer
  * stays valid as long as the handle; the characters behind it change with the next transform call. */
 const char* T360_lastKernel(VideoFrameTransform* transform);
+/* How the most recent call's low-pass stage was launched: "merged" (the planes of a batch in one launch), "per-plane", or ""
+ * (no low-pass yet).  For tests that pin a path. */
+const char* T360_lastLowpassPath(VideoFrameTransform* transform);
 /* Gather plan of `map_index` (the one long batches use): stats8 = staged tiles, direct (unstaged) tiles, source bytes fetched per frame
  * by the staged tiles, bytes of LDS filled per frame (one copy), pixels in direct tiles, bytes of the tile
  * tables on the device, scatter tiles among the staged ones (0 in the shipped configuration), 0.  Returns 0 when the plane has no tile plan (it then uses the general gather). */

@@ -242,6 +242,9 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=
         assert t.synchronize()
         if fused:
             assert "remap_fused_kernel" in t.lastKernel(), t.lastKernel()   # the path under test ran
+        if ov.get("num_horizontal_segments") == 32 and dims[0] == 3840 and extra_pad == 0:
+            # BASELINE config 3 at full size: the Y, U and V low-pass of the batch is ONE launch (no test pinned it)
+            assert t.lastLowpassPath() == "merged", t.lastLowpassPath()
         if pipelined:
             assert t.setPipelineDepth(3)
             outs = [torch.full((n * lout.frame_bytes,), 0x5A, dtype=torch.uint8, device="cuda") for _ in range(3)]

@@ -44,6 +44,7 @@ def sim():
 @pytest.mark.parametrize("waves,pieces", [(8, 24), (4, 16), (8 | (1000 << 8) | (1 << 20), 24),   # the third: 256x8 tiles wherever they fit
                                           (8 | (4 << 24), 24), (8 | (2 << 24), 24),                 # scatter tiles, strips of 4 / 2 lines
                                           (4 | (1 << 20), 12),    # shapes compared by lines on 4 waves: what nearest maps run with
+                                          (8 | (1 << 20), 24),    # ... and on 8 waves: the fallback of a nearest map the 4-wave planner refuses
                                           (8 | (4 << 24), 1)])    # scatter groups that cannot be staged go back to rectangles
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gather_through_the_plan_reads_the_right_bytes(name, waves, pieces, sim, oracle_mod):

@@ -24,7 +24,7 @@ REFERENCE_SYMBOLS = (
 ADDITIVE_SYMBOLS = (
     "T360_version", "T360_deviceCount", "T360_setStream", "T360_useOwnStream", "T360_synchronize", "T360_transformFrames",
     "T360_filterPlane", "T360_getMapSize", "T360_copyMap", "T360_getSegmentCount", "T360_getSegment",
-    "T360_copySegmentKernels", "T360_fillNoise", "T360_lastKernel", "T360_getPlanStats", "T360_buildFlags",
+    "T360_copySegmentKernels", "T360_fillNoise", "T360_lastKernel", "T360_lastLowpassPath", "T360_getPlanStats", "T360_buildFlags",
     "T360_transformFramesPipelined", "T360_transformFramesPipelinedMany", "T360_setPipelineDepth", "T360_pipelineJoin", "T360_setFusedLowpass",
 )
 
@@ -103,5 +103,7 @@ def load():
     for name in ADDITIVE_SYMBOLS[1:]:
         getattr(L, name).restype = i
     L.T360_lastKernel.restype = C.c_char_p
+    L.T360_lastLowpassPath.argtypes = [vp]
+    L.T360_lastLowpassPath.restype = C.c_char_p
     _lib = L
     return L

@@ -180,6 +180,7 @@ T360_EXPORT int T360_copySegmentKernels(VideoFrameTransform* t, int map_index, i
 }
 
 T360_EXPORT const char* T360_lastKernel(VideoFrameTransform* t) { return t ? t->lastKernel() : ""; }
+T360_EXPORT const char* T360_lastLowpassPath(VideoFrameTransform* t) { return t ? t->lastLowpassPath() : ""; }
 
 T360_EXPORT int T360_getPlanStats(VideoFrameTransform* t, int map_index, int64_t* stats8) {
   if (!t || !stats8) return 0;

@@ -314,7 +314,9 @@ bool VideoFrameTransform::pipelineJoin() {
       if (!check(hipEventRecord(pipe_done_[k], pipe_streams_[k]), "hipEventRecord") ||
           !check(hipStreamWaitEvent(stream_, pipe_done_[k], 0), "hipStreamWaitEvent"))
         return false;
-      pipe_busy_[k] = false;
+      // pipe_busy_[k] stays set: the join is a DEVICE-side wait, the lane may still be executing, and quiesceLanes() /
+      // drainLanes() use the flag to decide whether anything can still read the per-map tables they are about to rewrite
+      // (ADVICE round 5).  Only a host-side wait (drainLanes, synchronize) clears it; a second join re-records the event.
     }
   pipe_next_ = 0;
   return true;
@@ -1285,6 +1287,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
       }
       if (ok && lowpass_mergeable(la, njobs)) {
         if (!check(launch_lowpass_multi(la, njobs, n_frames, stream_), "low-pass launch")) return false;
+        last_lowpass_ = "merged";
         for (int k = 0; k < njobs; k++) {
           const int bstride = (jobs[k].in_w + 255) & ~255;
           srcs[(size_t)k] = Src{blurred_[scratch_].as<uint8_t>() + offs[(size_t)k], (int64_t)bstride * jobs[k].in_h, bstride};
@@ -1292,6 +1295,7 @@ bool VideoFrameTransform::runPlanes(const PlaneJob* jobs, int njobs, int n_frame
         merged = true;
       }
     }
+    if (!merged) last_lowpass_ = "per-plane";
     const bool side = njobs > 1 && njobs <= 4;  // planes 1.. on their own streams beside plane 0
     if (side && !merged && !check(hipEventRecord(lp_fork_, stream_), "hipEventRecord")) return false;
     for (int k = 0; k < njobs && !merged; k++) {

@@ -70,6 +70,8 @@ class VideoFrameTransform {
   bool getSegment(int idx, int i, int* rect4, int* lens2, int* fixed_point) const;
   bool copySegmentKernels(int idx, int i, float* kx, float* ky) const;
   const char* lastKernel() const { return last_kernel_; }
+  // "merged" (Y, U and V of a batch in one lowpass_q8w_multi_kernel launch), "per-plane", or "" before the first low-pass
+  const char* lastLowpassPath() const { return last_lowpass_; }
   bool planStats(int idx, int64_t* stats8) const;
 
  private:
@@ -181,6 +183,7 @@ class VideoFrameTransform {
   int plan_wide_pct_ = 200, plan_strip_pct_ = 0, plan_band_ = -1, plan_row_pad_ = 0, plan_row_align_ = 8;  // PlanOptions
   int plan_wide256_pct_ = 0, plan_cost_lines_ = 0, plan_scatter_ = 0;
   bool use_tiled_ = true;
+  const char* last_lowpass_ = "";
   char last_kernel_[64] = "";  // gather kernel of the most recent launch (reporting); the buffer lives as long as the handle
   void setLastKernel(const char* name) { snprintf(last_kernel_, sizeof(last_kernel_), "%s", name); }
   bool use_fast_lowpass_ = true;

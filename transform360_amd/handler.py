@@ -165,6 +165,9 @@ class VideoFrameTransform:
         """Name of the gather kernel the most recent transform call launched."""
         return (self._l.T360_lastKernel(self._h) or b"").decode()
 
+    def lastLowpassPath(self):
+        return (self._l.T360_lastLowpassPath(self._h) or b"").decode()
+
     def planStats(self, map_index):
         """dict of the gather plan of `map_index`, or None when the plane uses the general gather."""
         st = (C.c_int64 * 8)()
