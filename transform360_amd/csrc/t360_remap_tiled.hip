@@ -765,6 +765,26 @@ __device__ __forceinline__ void direct_tile(const TiledArgs& a, const TiledPlane
       frames(std::true_type{});
     else
       frames(std::false_type{});
+  } else if constexpr (KS == 8) {
+    // Lanczos4: the 64 taps one stencil row at a time (8 byte loads in flight), wrapped columns set up once per pixel.  The
+    // generic sample<8>() unrolls all 64 loads and weights and made the whole kernel spill 18 VGPRs to scratch
+    // (`scratch=76` in the round-5 profiles); same sum, same rounding.
+    constexpr int H = KS / 2 - 1;
+    const int16_t* __restrict__ wt = a.wtab + (size_t)e.frac * (KS * KS);
+    int xo[KS];
+#pragma unroll
+    for (int c = 0; c < KS; c++) xo[c] = wrap_coord((int)e.ix - H + c, pl.sw);
+    for (int f = f0 + part; f < f1; f += nparts) {
+      const uint8_t* __restrict__ sf = pl.src + (size_t)f * pl.src_frame_bytes;
+      int sum = 1 << (kCoefBits - 1);
+#pragma unroll 1
+      for (int r = 0; r < KS; r++) {
+        const uint8_t* __restrict__ S = sf + (size_t)wrap_coord((int)e.iy - H + r, pl.sh) * pl.sstride;
+#pragma unroll
+        for (int c = 0; c < KS; c++) sum += (int)S[xo[c]] * (int)wt[r * KS + c];
+      }
+      d[(size_t)f * pl.dst_frame_bytes] = (uint8_t)sat_u8(sum >> kCoefBits);
+    }
   } else {
     for (int f = f0 + part; f < f1; f += nparts) {
       const int v = sample<KS, false>(pl.src + (size_t)f * pl.src_frame_bytes, pl.sw, pl.sh, pl.sstride, a.wtab, e);
