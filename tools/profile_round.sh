@@ -29,6 +29,11 @@ trace_cfg() {
 # launches 3-5 % slower than the ones a few minutes later -- profiles/r05_experiments/README.md call 12 -- and the committed trace average
 # must be comparable with the committed line)
 for CFG in 1 3 4; do trace_cfg $CFG; done
+# config 3 with the low-pass fused into the gather tiles (T360_setFusedLowpass; off by default): which launch takes what
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace3f" -o "$TAG" -- \
+    python "$R/bench.py" --config 3 --fused-lowpass --steps 10 --warmup 3 --no-cpu-baseline --no-host-abi --no-two-streams --no-native > "$OUT/trace3f.log" 2>&1
+cp "$OUT/trace3f/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_cfg3_fused_kernel_stats.csv" 2>/dev/null
+grep -h "^{\"metric\"" "$OUT/trace3f.log" | tail -1 > "$R/profiles/${TAG}_cfg3_fused_bench_under_rocprof.json"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace8" -o "$TAG" -- \
     python "$R/bench.py" --frames 8 --steps 20 --warmup 3 --no-cpu-baseline --no-host-abi --no-verify --no-two-streams --no-native > "$OUT/trace8.log" 2>&1
 cp "$OUT/trace8/${TAG}_kernel_stats.csv" "$R/profiles/${TAG}_8frames_kernel_stats.csv" 2>/dev/null
