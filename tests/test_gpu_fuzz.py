@@ -118,3 +118,32 @@ def test_random_batches_through_pipelined_calls(seed, oracle_mod):
     """the same random batches, then three more times through T360_transformFramesPipelined on three lanes (low-pass and
     supersample scratch per lane, overlapping launches): identical to the plain call, which is compared with the oracle"""
     test_random_batches_match_oracle(seed, oracle_mod, pipelined=True)
+
+
+_FUSED_RAN = []
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_lowpass_batches_with_the_fused_path(seed, oracle_mod):
+    """T360_setFusedLowpass over random low-pass contexts (MONO input: the only kind that fuses): segment grids from 1 x 1 to
+    16 x 32, kernel scale factors that push some bands beyond 7 taps (those tiles stay on the two-pass path inside the same
+    call), rotations, several output layouts, bilinear and bicubic, padded strides, 24-27 frames (the long-batch plan).
+    Bit-exact against the oracle whether or not anything fused; most seeds must have run the fused kernel."""
+    from tests.test_gpu_parity import _batch_case
+    from transform360_amd import handler as T
+    r = np.random.default_rng(9000 + seed)
+    ov = dict(interpolation_alg=int(r.choice([CUBIC, CUBIC, LINEAR])), enable_low_pass_filter=1,
+              output_layout=int(r.choice([LAYOUT_CUBEMAP_32, LAYOUT_CUBEMAP_32, LAYOUT_CUBEMAP_23_OFFCENTER, LAYOUT_EAC_32, LAYOUT_EQUIRECT])),
+              num_vertical_segments=int(r.choice([1, 3, 5, 9, 15, 16])), num_horizontal_segments=int(r.choice([1, 2, 4, 8, 32])),
+              adjust_kernel=int(r.random() < 0.7), kernel_height_scale_factor=float(np.float32(r.choice([0.5, 1.0, 1.0, 2.0]))),
+              expand_coef=float(np.float32(r.choice([1.0, 1.01]))))
+    if r.random() < 0.4:
+        ov.update(fixed_yaw=float(np.float32(r.uniform(-180, 180))), fixed_pitch=float(np.float32(r.uniform(-90, 90))),
+                  fixed_roll=float(np.float32(r.uniform(-30, 30))))
+    in_w, in_h = int(r.integers(20, 60)) * 32, int(r.integers(12, 40)) * 16
+    out_w, out_h = int(r.integers(6, 16)) * 48, int(r.integers(6, 16)) * 32
+    n = int(r.choice([24, 25, 27]))
+    ran = _batch_case(T, oracle_mod, ov, n=n, dims=(in_w, in_h, out_w, out_h), extra_pad=int(r.choice([0, 0, 64])), threads=8, fused="try")
+    _FUSED_RAN.append(bool(ran))
+    if seed == 39:
+        assert sum(_FUSED_RAN) >= 20, "only %d of %d random low-pass contexts ran the fused kernel" % (sum(_FUSED_RAN), len(_FUSED_RAN))

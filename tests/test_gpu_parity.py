@@ -240,8 +240,9 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=
         assert t.setStream(torch.cuda.current_stream())
         assert t.transformFrames(d_in, lin.frame_bytes, d_out, lout.frame_bytes, n, t.plane_descs(lin, lout))
         assert t.synchronize()
-        if fused:
+        if fused is True:
             assert "remap_fused_kernel" in t.lastKernel(), t.lastKernel()   # the path under test ran
+        ran_fused = "remap_fused_kernel" in t.lastKernel()
         if ov.get("num_horizontal_segments") == 32 and dims[0] == 3840 and extra_pad == 0:
             # BASELINE config 3 at full size: the Y, U and V low-pass of the batch is ONE launch (no test pinned it)
             assert t.lastLowpassPath() == "merged", t.lastLowpassPath()
@@ -266,6 +267,7 @@ def _batch_case(T, O, ov, n=5, dims=(960, 480, 384, 256), extra_pad=64, threads=
                 want = np.full((lout.dims[p][1], lout.dims[p][0]), 0x5A, np.uint8)
                 assert o.transformFramePlane(lin.plane_view(fin, p), want, 1 if p else 0, p)
                 assert np.array_equal(lout.plane_view(fout, p), want), (k, p)
+    return ran_fused
 
 
 def test_batch_equals_per_plane_calls(T, oracle_mod):
