@@ -721,6 +721,13 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
     path.step(F)
     path.sync()
     first_step_ms = (time.perf_counter() - t_first) * 1e3
+    # what a stream that starts cold sees (VERDICT round 5, weak point 9): the 8 steps right behind the first one, before any
+    # clock warm-up -- plans exist, clocks and caches do not
+    t_c = time.perf_counter()
+    warm_steps(F, 8)
+    path.sync()
+    cold_ms_per_step = (time.perf_counter() - t_c) * 1e3 / 8
+    busy["s"] += time.perf_counter() - t_c
     t_w = time.perf_counter()
     while path.name == "hip" and time.perf_counter() - t_w < CLOCK_WARMUP_S:
         warm_steps(F, 8, clock_warmup_steps)
@@ -1034,7 +1041,8 @@ def run_rank(args, Path, dist, rank, world, coll_dev, wl, ctx):
             "fps": round(fps, 1),
             # cold and warm-up figures next to the timed ones (VERDICT round 5, weak point 9): the first call after init plans
             # the gather on the host; `clock_warmup_steps` untimed steps then bring the clocks up before the W warm-up steps
-            "first_step_ms": round(first_step_ms, 1), "clock_warmup_steps": clock_warmup_steps,
+            "first_step_ms": round(first_step_ms, 1), "cold_ms_per_step_steps_2_to_9": round(cold_ms_per_step, 4),
+            "clock_warmup_steps": clock_warmup_steps,
             "library_sha16": lib_sha,
             "repeats": REPEATS, "repeats_ms_per_step": [round(r[0] / args.steps * 1e3, 4) for r in (sruns if headline_strong else runs)],
             "input_ring": {"groups_of_F_frames": getattr(path, "groups", 1), "bytes": getattr(path, "groups", 1) * F * lin.frame_bytes,
